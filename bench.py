@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Decode-step benchmark for the MI355X decode attention path.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10            # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W    # N GPUs, one rank per GPU (RCCL)
+
+One step = one decode step of the continuous batch on synthetic state already resident in HBM:
+attention block (projection GEMM with page gather/scatter -> q.K^T -> masked softmax -> softmax.V)
+followed by the greedy decoder head, i.e. what PagedAttentionInferenceModel::forward does per
+iteration with n_new_items = 0 (reference src/inference_model.cpp:52-82).  Every rank owns an
+independent shard of the batch rows (weak scaling); the only cross-GPU traffic is the all-gather of
+the generated token ids.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from min_llm_inference_amd import ops  # noqa: E402
+
+PAGE = 16
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (layout, rows per GPU, emb_dim, max_seq) -- BASELINE.json configs[1..3]
+    "c2": ("naive", 256, 256, 1024),
+    "c3": ("paged", 256, 256, 1024),
+    "c4": ("paged", 1024, 512, 4096),
+}
+N_VOCAB = 1024
+
+
+class Workload:
+    """Synthetic decode state for one GPU (weights U(-1,1)/sqrt(D), lengths U[S/4, 3S/4],
+    pages drawn from a shuffled pool)."""
+
+    def __init__(self, name, dev, seed, headroom):
+        self.name = name
+        self.layout, self.B, self.D, self.S = WORKLOADS[name]
+        B, D, S = self.B, self.D, self.S
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        self.dev = dev
+        lengths = rng.integers(S // 4, 3 * S // 4 + 1, size=B).astype(np.int32)
+        assert int(lengths.max()) + headroom + 2 < S
+        self.lengths_host = lengths
+        self.lengths = torch.from_numpy(lengths).to(dev)
+        self.lengths0 = self.lengths.clone()
+
+        def u(*shape, scale=1.0):
+            return (torch.rand(*shape, device=dev, generator=g) * 2 - 1) * scale
+
+        sc = 1.0 / np.sqrt(D)
+        self.wk, self.wq, self.wv = (u(D, D, scale=sc) for _ in range(3))
+        self.emb_table = u(N_VOCAB, D)
+        self.emb_table[ops.EOF_TOKEN_ID] = 0  # EOF never wins the argmax: the batch stays full while timing
+        self.wpe = u(S, D)
+        self.q_output = torch.zeros(B, D, device=dev)
+        self.qkt_output = torch.zeros(B, S, device=dev)
+        self.attention_result = torch.zeros(B, D, device=dev)
+        self.emb_score = torch.zeros(B, N_VOCAB, device=dev)
+        self.decoder_result = torch.full((B, 1), -1, dtype=torch.int32, device=dev)
+        self.new_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        if self.layout == "paged":
+            W = S // PAGE
+            per_row = [-(-(int(L) + headroom + 2) // PAGE) for L in lengths]
+            total = sum(per_row)
+            block = PAGE * 3 * D
+            self.pool = torch.empty(total * block, device=dev)
+            chunk = 1 << 28
+            for o in range(0, self.pool.numel(), chunk):  # K/V/x contents: U(-1,1)
+                n = min(chunk, self.pool.numel() - o)
+                self.pool[o:o + n] = u(n)
+            order = rng.permutation(total)
+            table = np.zeros((B, W), np.int64)
+            cur = 0
+            base = self.pool.data_ptr()
+            for b in range(B):
+                table[b, :per_row[b]] = base + 4 * block * order[cur:cur + per_row[b]].astype(np.int64)
+                cur += per_row[b]
+            self.page_table = torch.from_numpy(table).to(dev)
+            self.kv_bytes_resident = self.pool.numel() * 4
+        else:
+            self.inp_embedding = u(B, S, D)
+            self.kt_cache = u(B, D, S)
+            self.v_cache = u(B, S, D)
+        ops.workspace_for(B, S, D, dev)  # allocate scratch outside the timed region
+        torch.cuda.synchronize()
+
+    def attention(self):
+        if self.layout == "paged":
+            ops.paged_attention(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx, self.q_output,
+                                self.qkt_output, self.attention_result, 0, self.S)
+        else:
+            ops.inference_self_attention(self.inp_embedding, self.lengths, self.wk, self.wq, self.wv, self.new_idx,
+                                         self.kt_cache, self.v_cache, self.q_output, self.qkt_output,
+                                         self.attention_result, 0)
+
+    def decoder(self):
+        if self.layout == "paged":
+            ops.launch_paged_attention_decoder_multi_rounds(self.attention_result, self.emb_table, self.emb_score,
+                                                            self.wpe, self.page_table, self.lengths,
+                                                            self.decoder_result, 0)
+        else:
+            ops.launch_decoder(self.attention_result, self.emb_table, self.emb_score, self.wpe, self.inp_embedding,
+                               self.lengths, self.decoder_result.view(-1))
+
+    def step(self):
+        self.attention()
+        self.decoder()
+
+    # ---- the individual kernels, for the roofline pass ------------------------------------
+    def kernels(self):
+        w = self
+        if self.layout == "paged":
+            return {
+                "get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention(
+                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
+                "qkt_paged": lambda: ops.launch_qkt_paged_attention(w.q_output, w.page_table, w.lengths, w.qkt_output),
+                "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
+                "softmax_v_paged": lambda: ops.launch_softmax_v_paged_attention(w.qkt_output, w.page_table,
+                                                                                w.attention_result, w.lengths),
+            }
+        return {
+            "get_latest_kt_q_v (MFMA GEMM)": lambda: ops.launch_get_latest_kt_q_v(
+                w.inp_embedding, w.lengths, w.wk, w.wq, w.wv, w.kt_cache, w.v_cache, w.q_output),
+            "qkt": lambda: ops.launch_qkt(w.q_output, w.kt_cache, w.lengths, w.qkt_output),
+            "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
+            "softmax_v": lambda: ops.launch_softmax_v(w.qkt_output, w.v_cache, w.attention_result, w.lengths),
+        }
+
+    def algorithmic_bytes(self, lengths):
+        """Per-launch algorithmic HBM bytes (DESIGN.md 'Roofline accounting'); e = 4 bytes (fp32)."""
+        L = lengths.astype(np.int64)
+        B, D = self.B, self.D
+        live = int((L > 0).sum())
+        ptrs = int((8 * -(-L // PAGE)).sum()) if self.layout == "paged" else 0
+        kv_one = int(L.sum()) * D * 4
+        qkt = kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4       # K + q in, scores out
+        sv = kv_one + int(L.sum()) * 4 + live * D * 4 + ptrs + B * 4        # V + probs in, result out
+        latest = live * D * 4 * 4 + 3 * D * D * 4 + B * 4 + (8 * live if self.layout == "paged" else 0)
+        step = (2 * kv_one + live * (3 * D * 4 + D * 4) + 3 * D * D * 4 + B * 4 + ptrs)
+        return {"qkt": qkt, "softmax_v": sv, "get_latest": latest, "step": step}
+
+
+def time_kernel(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps  # ms, on the stream the kernels were launched on
+
+
+def measure_copy_gbs(dev):
+    n = 1 << 28  # 1 GiB of floats in, 1 GiB out
+    a = torch.empty(n, device=dev)
+    b = torch.empty(n, device=dev)
+    a.uniform_()
+    ms = time_kernel(lambda: ops.stream_copy(a, b), 10)
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The CPU oracle (single-threaded port of the reference's host functions) on a bounded row sample of the
+    same workload, contiguous layout (the reference has no CPU paged path), decode step only (n_new = 0)."""
+    import oracle
+    D, S = wl.D, wl.S
+    rows = 8
+    rng = np.random.default_rng(1)
+
+    def run(n):
+        L = wl.lengths_host[:n].copy()
+        inp = rng.random((n, S, D), dtype=np.float32)
+        kt = rng.random((n, D, S), dtype=np.float32)
+        v = rng.random((n, S, D), dtype=np.float32)
+        w = [((rng.random((D, D), dtype=np.float32) * 2 - 1) / np.sqrt(D)).astype(np.float32) for _ in range(3)]
+        q = np.zeros((n, D), np.float32)
+        s = np.zeros((n, S), np.float32)
+        o = np.zeros((n, D), np.float32)
+        idx = np.zeros((n,), np.int32)
+        t0 = time.perf_counter()
+        oracle.self_attention_inference_host(inp, L, w[0], w[1], w[2], idx, kt, v, q, s, o, 0)
+        return time.perf_counter() - t0, int((L > 0).sum())
+
+    t, live = run(rows)
+    per_row = t / max(live, 1)
+    n = int(min(wl.B, max(rows, budget_s / max(per_row, 1e-9)), 4e9 // (3 * S * D * 4)))
+    t, live = run(n)
+    return {"value": live / t, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of {wl.B} rows of the same workload (contiguous layout, decode step only), "
+                      f"{t:.1f} s single-threaded oracle_cpu.c"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+
+    cfg_index = sorted(WORKLOADS).index(args.workload) + 1
+    wl = Workload(args.workload, dev, 0x5EED0000 + cfg_index * 16 + rank, headroom=args.steps + args.warmup + 8)
+    tokens_all = torch.empty(world * wl.B, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        wl.step()
+        if world > 1:  # the path's only exchange: generated token ids (4 KiB per rank at B=1024)
+            dist.all_gather_into_tensor(tokens_all, wl.decoder_result.view(-1))
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # every row must still be live, otherwise "tokens" below would over-count
+    grown = (wl.lengths - wl.lengths0).cpu().numpy()
+    assert (grown == args.steps + args.warmup).all(), "a row finished during the timed region"
+    tokens = torch.tensor([float(wl.B * args.steps)], device=dev)
+    tmax = torch.tensor([elapsed], device=dev)
+    if world > 1:
+        dist.all_reduce(tokens, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    total_tokens = float(tokens.item())
+
+    out = {
+        "metric": "decode tokens/sec (whole node) on synthetic batch",
+        "value": total_tokens / elapsed,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
+                        f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[S/4,3S/4], fp32",
+            "rows_per_gpu": wl.B, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
+            "mean_length": float(wl.lengths_host.mean()),
+            "parallelism": f"row-sharded replicas x{world}, all-gather of token ids",
+        },
+    }
+
+    if rank == 0 and not args.no_roofline:
+        lengths_now = wl.lengths.cpu().numpy()
+        alg = wl.algorithmic_bytes(lengths_now)
+        times = {}
+        for name, fn in wl.kernels().items():
+            times[name] = time_kernel(fn, max(10, args.steps))
+        wl.lengths.copy_(torch.from_numpy(lengths_now).to(dev))
+        key_of = {"qkt": [k for k in times if k.startswith("qkt")][0],
+                  "softmax_v": [k for k in times if k.startswith("softmax_v")][0]}
+        dom = max(key_of, key=lambda k: times[key_of[k]])
+        ms = times[key_of[dom]]
+        achieved = alg[dom] / (ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms,
+            "kernel_ms": times,
+            "step_algorithmic_bytes": alg["step"],
+            "step_gbs": alg["step"] / (out["ms_per_step"] * 1e-3) / 1e9,
+            "measured_copy_gbs": measure_copy_gbs(dev),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

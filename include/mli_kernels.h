@@ -1,0 +1,179 @@
+/*
+ * mli_kernels.h -- C ABI of libmli_hip.so, the MI355X (gfx950) implementation of the
+ * single-block self-attention decode path of xyg-coder/min_llm_inference.
+ *
+ * This header is the drop-in boundary.  The reference has no FFI layer: its boundary is
+ * the C++ `launch_*` free functions declared in the headers under include/kernels/ (reference paths
+ * below are relative to the reference repository root).  Every entry point here is the
+ * POD form of exactly one of those functions; the C++ adapters with the reference's own
+ * signatures live in min_llm_inference_amd/host/src/launchers.cpp and only unpack
+ * Tensor shapes before calling into this ABI.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - every buffer is caller-owned and pre-allocated; no entry point allocates, frees
+ *     or synchronises (all are legal inside hipGraph capture);
+ *   - `stream` is a hipStream_t passed as void*; NULL = the legacy default stream,
+ *     which is what the reference launches on;
+ *   - return value: 0 on success, a positive hipError_t when a launch failed, or
+ *     MLI_ERR_BAD_ARG when a shape precondition the reference asserts on is violated;
+ *   - indices are int32 as in the reference, offsets are computed in 64 bit;
+ *   - page layout (reference include/utils.h:32-60): a page block holds
+ *     PAGE_BLOCK_SIZE=16 tokens, float offset inside a block =
+ *     (s % 16) * 3 * emb_dim + seg * emb_dim + d, seg 0 = input embedding, 1 = K, 2 = V;
+ *     page table entry index = b * (n_sequence / 16) + s / 16.
+ */
+#ifndef MLI_KERNELS_H
+#define MLI_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLI_PAGE_BLOCK_SIZE 16
+#define MLI_EMPTY_ROW_TOKEN_ID (-1)
+#define MLI_EOF_TOKEN_ID 1023
+#define MLI_ERR_BAD_ARG (-22)
+#define MLI_ERR_WORKSPACE (-12)
+
+/* ABI version; bumped whenever a signature below changes. */
+int mli_abi_version(void);
+
+/* Bytes of device scratch the split-sequence kernels need for a problem of this size.
+ * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention). */
+size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim);
+
+/* ------------------------------------------------------------------------------------
+ * Contiguous ("naive") KV-cache path.
+ *   inp_embedding [n_batch, n_sequence, input_dim]   kt_cache [n_batch, output_dim, n_sequence]
+ *   v_cache       [n_batch, n_sequence, output_dim]  wk/wq/wv [input_dim, output_dim]
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces launch_fill_new_kt_v_cache  (include/kernels/self_attention_inference_optimized.h:5-8,
+ * src/kernels/self_attention_inference_optimized.cu:303-323).  No-op when n_new_items == 0. */
+int mli_fill_new_kt_v_cache(const float* inp_embedding, const int* new_batch_idx, const int* lengths,
+                            const float* wk, const float* wv, float* kt_cache, float* v_cache,
+                            int n_batch, int n_sequence, int input_dim, int output_dim,
+                            int n_new_items, void* stream);
+
+/* replaces launch_get_latest_kt_q_v  (…optimized.h:11-15, …optimized.cu:325-343).
+ * Rows with lengths[b]==0 are left untouched (q_output included). */
+int mli_get_latest_kt_q_v(const float* inp_embedding, const int* lengths,
+                          const float* wk, const float* wq, const float* wv,
+                          float* kt_cache, float* v_cache, float* q_output,
+                          int n_batch, int n_sequence, int input_dim, int output_dim, void* stream);
+
+/* replaces launch_qkt  (…optimized.h:17-19, …optimized.cu:345-358).
+ * qkt_output[b, s] for s >= lengths[b] is not written. */
+int mli_qkt(const float* q_output, const float* kt_cache, const int* lengths, float* qkt_output,
+            int n_batch, int n_sequence, int dim, void* stream);
+
+/* replaces launch_softmax_in_place_with_lengths  (…optimized.h:21-22, …optimized.cu:360-368).
+ * Requires n_sequence % 4 == 0 (reference device assert, …optimized.cu:195).  Writes the whole
+ * row: probabilities for s < lengths[b], 0 for the tail. */
+int mli_softmax_in_place_with_lengths(float* qkt_output, const int* lengths,
+                                      int n_batch, int n_sequence, void* stream);
+
+/* replaces launch_softmax_v  (…optimized.h:24-26, …optimized.cu:370-383).
+ * workspace may be NULL when mli_attention_workspace_bytes() returns 0. */
+int mli_softmax_v(const float* softmax_result, const float* v_cache, const int* lengths,
+                  float* attention_result, int n_batch, int n_sequence, int output_dim,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces inference_self_attention  (…optimized.h:28-48, …optimized.cu:282-301):
+ * fill -> latest -> qkt -> softmax -> softmax_v on one stream. */
+int mli_inference_self_attention(const float* inp_embedding, const int* lengths,
+                                 const float* wk, const float* wq, const float* wv,
+                                 const int* new_batch_idx, float* kt_cache, float* v_cache,
+                                 float* q_output, float* qkt_output, float* attention_result,
+                                 int n_batch, int n_sequence, int input_dim, int output_dim,
+                                 int n_new_items, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Paged KV-cache path.  page_table is float*[n_batch][n_sequence/16] of device pointers.
+ * Requires n_sequence % 16 == 0 and emb_dim % 4 == 0 (reference asserts,
+ * src/kernels/paged_attention.cu:105-107, src/kernels/paged_attention_cublas.cu:212).
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces launch_fill_new_k_v_cache_paged_attention (include/kernels/paged_attention.h:28-30,
+ * src/kernels/paged_attention.cu:96-115) AND launch_fill_new_k_v_cache_paged_attention_warp_tiling
+ * (paged_attention.h:65-67, src/kernels/paged_attention_cublas.cu:225-246): one MFMA kernel. */
+int mli_fill_new_k_v_cache_paged(float* const* page_table, const int* new_batch_idx, const int* lengths,
+                                 const float* wk, const float* wv,
+                                 int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream);
+
+/* replaces launch_get_latest_k_q_v_paged_attention (paged_attention.h:32-35, paged_attention.cu:188-199)
+ * AND launch_get_latest_k_q_v_paged_attention_cublas (paged_attention.h:57-63,
+ * paged_attention_cublas.cu:76-99: gather + 3 cublasSgemm + scatter) as one gather-GEMM-scatter kernel. */
+int mli_get_latest_k_q_v_paged(float* const* page_table, const int* lengths,
+                               const float* wk, const float* wq, const float* wv, float* q_output,
+                               int n_batch, int n_sequence, int emb_dim, void* stream);
+
+/* replaces launch_qkt_paged_attention (paged_attention.h:37-39, paged_attention.cu:270-280). */
+int mli_qkt_paged(const float* q_output, const float* const* page_table, const int* lengths,
+                  float* qkt_output, int n_batch, int n_sequence, int emb_dim, void* stream);
+
+/* replaces launch_softmax_v_paged_attention (paged_attention.h:41-43, paged_attention.cu:333-345). */
+int mli_softmax_v_paged(const float* softmax_result, const float* const* page_table, const int* lengths,
+                        float* attention_result, int n_batch, int n_sequence, int emb_dim,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces paged_attention (paged_attention.h:17-25, paged_attention.cu:358-377) and
+ * paged_attention_with_cublas (paged_attention.h:46-54, paged_attention_cublas.cu:260-280).
+ * On return q_output, qkt_output (probabilities, zero tail) and attention_result hold what the
+ * reference's five launches leave there. */
+int mli_paged_attention(float* const* page_table, const int* lengths,
+                        const float* wk, const float* wq, const float* wv, const int* new_batch_idx,
+                        float* q_output, float* qkt_output, float* attention_result,
+                        int n_batch, int n_sequence, int emb_dim, int n_new_items,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Encoder / decoder head (needed for InferenceModel::forward).
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces launch_inference_optimized_encoder_kernel (include/kernels/encoder.h:16-19,
+ * src/kernels/encoder.cu:80-92). */
+int mli_inference_optimized_encoder(const float* emb_table, const float* wpe, const int* inp,
+                                    float* inp_embedding, const int* lengths, const int* new_item_indices,
+                                    int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream);
+
+/* replaces launch_paged_attention_encoder_kernel (encoder.h:22-25, encoder.cu:134-147). */
+int mli_paged_attention_encoder(const float* emb_table, const float* wpe, const int* inp,
+                                float* const* page_table, const int* lengths, const int* new_item_indices,
+                                int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream);
+
+/* replaces launch_decoder (include/kernels/decoder.h:19-23, src/kernels/decoder.cu:94-111):
+ * emb_score = batch_result . emb_table^T, per-row argmax, lengths update, next embedding write. */
+int mli_decoder(const float* batch_result, const float* emb_table, float* emb_score, const float* wpe_table,
+                float* inp_embedding, int* lengths, int* decoder_result,
+                int n_batch, int n_vocab, int n_sequence, int emb_dim, void* stream);
+
+/* replaces launch_paged_attention_decoder_multi_rounds and
+ * launch_paged_attention_cublas_decoder_multi_rounds (decoder.h:26-37, decoder.cu:207-255). */
+int mli_paged_decoder_multi_rounds(const float* batch_result, const float* emb_table, float* emb_score,
+                                   const float* wpe_table, float* const* page_table, int* lengths,
+                                   int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                                   int n_decoder_results, int i_decoder, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Test / measurement support (not on the reference's product path).
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces launch_clone_inp_embedding_k_v_cache (include/utils.h:101-103, src/kernels/utils.cu:230-239):
+ * copies contiguous inp/kt/v tensors into the pages of every non-empty row, positions
+ * 0..min(length, n_sequence-1) inclusive. */
+int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp_embedding,
+                                      const float* kt_cache, const float* v_cache, const int* lengths,
+                                      int n_batch, int n_sequence, int emb_dim, void* stream);
+
+/* float4 device copy used by bench.py to measure the achievable HBM copy rate on the box. */
+int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLI_KERNELS_H */

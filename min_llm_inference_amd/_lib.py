@@ -1,0 +1,66 @@
+"""ctypes loader for libmli_hip.so (C ABI: include/mli_kernels.h, include/mli_engine.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MliError(RuntimeError):
+    """Raised when a C-ABI call returns non-zero (the reference throws std::runtime_error("Cuda Failure"))."""
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libmli_hip.so")
+
+
+def load_library():
+    """Load the HIP library.  There is deliberately no fallback: a missing .so is a hard error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise MliError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(path)
+    _declare(lib)
+    _LIB = lib
+    return lib
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_Z = ctypes.c_size_t
+
+# name -> argtypes; restype is int unless listed in _RESTYPES.  Mirrors include/mli_kernels.h 1:1.
+SIGNATURES = {
+    "mli_abi_version": [],
+    "mli_attention_workspace_bytes": [_I, _I, _I],
+    "mli_fill_new_kt_v_cache": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mli_get_latest_kt_q_v": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mli_qkt": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "mli_softmax_in_place_with_lengths": [_P, _P, _I, _I, _P],
+    "mli_softmax_v": [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
+    "mli_inference_self_attention": [_P] * 11 + [_I] * 5 + [_P, _Z, _P],
+    "mli_fill_new_k_v_cache_paged": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mli_get_latest_k_q_v_paged": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mli_qkt_paged": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "mli_softmax_v_paged": [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
+    "mli_paged_attention": [_P] * 9 + [_I] * 4 + [_P, _Z, _P],
+    "mli_inference_optimized_encoder": [_P] * 6 + [_I] * 4 + [_P],
+    "mli_paged_attention_encoder": [_P] * 6 + [_I] * 4 + [_P],
+    "mli_decoder": [_P] * 7 + [_I] * 4 + [_P],
+    "mli_paged_decoder_multi_rounds": [_P] * 7 + [_I] * 6 + [_P],
+    "mli_clone_inp_embedding_k_v_cache": [_P] * 5 + [_I] * 3 + [_P],
+    "mli_stream_copy": [_P, _P, _Z, _P],
+}
+_RESTYPES = {"mli_attention_workspace_bytes": _Z}
+
+
+def _declare(lib):
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _I)

@@ -1,0 +1,468 @@
+// HBM-bound half of the decode step: q.K^T scores, length-masked softmax, softmax.V.
+// Contiguous ("naive") and paged KV layouts.  Reference behaviour being replaced:
+//   src/kernels/self_attention_inference_optimized.cu:150-279 (qkt, softmax_in_place_with_lengths, softmax_v)
+//   src/kernels/paged_attention.cu:208-345                    (qkt_paged_attention, softmax_v_paged_attention)
+//
+// Design (gfx950): one wave owns whole K/V rows -- 64 lanes x float4 = 1 KiB contiguous per
+// load instruction -- so every HBM request is a full row piece; the page pointers of a
+// workgroup's sequence chunk are staged once in LDS; per-row dot products are reduced with a
+// transposing wave butterfly (17 exchanges per 16 tokens); the sequence is cut into fixed-size
+// chunks (grid.x) so that ragged row lengths still give evenly sized work units, with a tiny
+// fixed-order combine pass for softmax.V (bitwise reproducible, no float atomics).
+#include "device_common.hpp"
+
+namespace mli {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanWaves = kScanThreads / kWave;
+constexpr int kMaxChunkTokens = 1024;
+constexpr int kMinChunkTokens = 64;
+
+// Sequence chunk (tokens per workgroup) for the split-sequence kernels: the largest
+// power of two in [64, 1024] that still yields >= 8192 work units.
+// MLI_CHUNK_TOKENS (power of two in [64, 1024]) overrides the heuristic for tuning runs.
+static int pick_chunk_tokens(int n_batch, int n_sequence) {
+    static const int forced = [] {
+        const char* e = getenv("MLI_CHUNK_TOKENS");
+        const int v = e ? atoi(e) : 0;
+        return (v >= kMinChunkTokens && v <= kMaxChunkTokens && (v & (v - 1)) == 0) ? v : 0;
+    }();
+    if (forced) return forced;
+    int ct = kMaxChunkTokens;
+    while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < 8192) ct >>= 1;
+    return ct;
+}
+
+// ------------------------------------------------------------------------------------------
+// qkt, paged layout.  grid = (ceil(S / ct), B), block = 256.  Each wave takes whole pages.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
+    const float* __restrict__ q, const float* const* __restrict__ page_table,
+    const int* __restrict__ lengths, float* __restrict__ qkt, int S, int D, int ct) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int b = blockIdx.y;
+    const int L = lengths[b];
+    const int s0 = blockIdx.x * ct;
+    if (s0 >= L) return;  // same early exit as the reference (paged_attention.cu:233-235)
+
+    const int W = S / kPage;
+    const int D4 = D >> 2;
+    const int s1 = min(s0 + ct, L);
+    const int npages = (s1 - s0 + kPage - 1) / kPage;
+
+    float4* q_sh = reinterpret_cast<float4*>(smem_raw);                                  // D4 float4
+    const float** ptr_sh = reinterpret_cast<const float**>(smem_raw + (size_t)D4 * 16);  // ct/16 pointers
+
+    const float4* q4 = reinterpret_cast<const float4*>(q + (int64_t)b * D);
+    for (int i = threadIdx.x; i < D4; i += kScanThreads) q_sh[i] = q4[i];
+    for (int i = threadIdx.x; i < npages; i += kScanThreads)
+        ptr_sh[i] = page_table[(int64_t)b * W + s0 / kPage + i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const float scale = sqrtf((float)D);  // the reference divides by sqrtf(dim), so do we
+    const int nj = (D4 + kWave - 1) / kWave;
+
+    for (int pi = wave; pi < npages; pi += kScanWaves) {
+        const float* page = ptr_sh[pi];
+        const float* krow = page + D;  // segment 1 of token slot 0
+        float acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int j = 0; j < nj; ++j) {
+            const int i4 = lane + j * kWave;
+            if (i4 < D4) {
+                const float4 qv = q_sh[i4];
+                float4 kv[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    kv[t] = *reinterpret_cast<const float4*>(krow + (int64_t)t * 3 * D + (int64_t)i4 * 4);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[t] = dot4(qv, kv[t], acc[t]);
+            }
+        }
+        const float tot = wave_reduce16(acc, lane);
+        const int s = s0 + pi * kPage + (lane >> 2);
+        if ((lane & 3) == 0 && s < L) qkt[(int64_t)b * S + s] = tot / scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// qkt, contiguous layout kt_cache[B, D, S].  Lanes run along s (float4 = 4 tokens per lane);
+// the 4 waves of a workgroup split d and are summed in fixed order through LDS.
+// grid = (ceil(S / 256), B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
+    const float* __restrict__ q, const float* __restrict__ kt, const int* __restrict__ lengths,
+    float* __restrict__ qkt, int S, int D) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4 (*red)[kWave] = reinterpret_cast<float4 (*)[kWave]>(smem_raw);                // [waves][64] float4
+    float* q_sh = reinterpret_cast<float*>(smem_raw + sizeof(float4) * kScanWaves * kWave);  // D floats
+    const int b = blockIdx.y;
+    const int L = lengths[b];
+    const int s0 = blockIdx.x * 256;
+    if (s0 >= L) return;  // reference …optimized.cu:160-162
+    for (int i = threadIdx.x; i < D; i += kScanThreads) q_sh[i] = q[(int64_t)b * D + i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int s = s0 + lane * 4;  // S % 4 == 0, so a float4 never straddles the row end
+    const bool in_row = s < S && s < L;
+    const float* base = kt + (int64_t)b * D * S + s;
+    const int d_per_wave = (D + kScanWaves - 1) / kScanWaves;
+    const int d0 = wave * d_per_wave;
+    const int d1 = min(d0 + d_per_wave, D);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_row) {
+        int d = d0;
+        for (; d + 8 <= d1; d += 8) {
+            float4 kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const float4*>(base + (int64_t)(d + u) * S);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) axpy4(q_sh[d + u], kv[u], acc);
+        }
+        for (; d < d1; ++d) axpy4(q_sh[d], *reinterpret_cast<const float4*>(base + (int64_t)d * S), acc);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && in_row) {
+        float4 r = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < kScanWaves; ++w) {
+            r.x += red[w][lane].x; r.y += red[w][lane].y; r.z += red[w][lane].z; r.w += red[w][lane].w;
+        }
+        const float scale = sqrtf((float)D);
+        float* out = qkt + (int64_t)b * S + s;
+        const float v[4] = {r.x / scale, r.y / scale, r.z / scale, r.w / scale};
+        if (s + 4 <= L) {
+            *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int u = 0; u < 4; ++u) if (s + u < L) out[u] = v[u];   // never write past lengths[b]
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked softmax in place, one wave per row, float4 traffic.  block = 256 (4 rows).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void softmax_lengths_kernel(
+    float* __restrict__ qkt, const int* __restrict__ lengths, int B, int S) {
+    const int row = blockIdx.x * kScanWaves + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int L = min(lengths[row], S);
+    float4* rp = reinterpret_cast<float4*>(qkt + (int64_t)row * S);
+    const int n4_len = (L + 3) >> 2;
+    const int n4 = S >> 2;
+
+    float m = -INFINITY;
+    for (int i = lane; i < n4_len; i += kWave) {
+        const float4 v = rp[i];
+        const int s = i * 4;
+        m = fmaxf(m, v.x);
+        if (s + 1 < L) m = fmaxf(m, v.y);
+        if (s + 2 < L) m = fmaxf(m, v.z);
+        if (s + 3 < L) m = fmaxf(m, v.w);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int i = lane; i < n4_len; i += kWave) {
+        const float4 v = rp[i];
+        const int s = i * 4;
+        sum += expf(v.x - m);
+        if (s + 1 < L) sum += expf(v.y - m);
+        if (s + 2 < L) sum += expf(v.z - m);
+        if (s + 3 < L) sum += expf(v.w - m);
+    }
+    sum = wave_sum(sum);
+    for (int i = lane; i < n4; i += kWave) {
+        const int s = i * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < L) {
+            const float4 v = rp[i];
+            o.x = expf(v.x - m) / sum;
+            if (s + 1 < L) o.y = expf(v.y - m) / sum;
+            if (s + 2 < L) o.z = expf(v.z - m) / sum;
+            if (s + 3 < L) o.w = expf(v.w - m) / sum;
+        }
+        rp[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax.V partial sums.  VEC floats per lane per load (4 when rows are 16-byte aligned),
+// NJ loads per row slice; grid = (nchunks, B, d_slices).  A slice covers 64*VEC*NJ columns.
+// direct != 0: single chunk per row, result goes straight to attention_result.
+// ------------------------------------------------------------------------------------------
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ void vfma(float p, const typename VecT<VEC>::type& v, typename VecT<VEC>::type& acc);
+template <> __device__ __forceinline__ void vfma<4>(float p, const float4& v, float4& acc) { axpy4(p, v, acc); }
+template <> __device__ __forceinline__ void vfma<1>(float p, const float& v, float& acc) { acc = fmaf(p, v, acc); }
+
+template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type vzero();
+template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+template <int VEC> __device__ __forceinline__ void vadd(typename VecT<VEC>::type& a, const typename VecT<VEC>::type& b);
+template <> __device__ __forceinline__ void vadd<4>(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+template <> __device__ __forceinline__ void vadd<1>(float& a, const float& b) { a += b; }
+
+template <int VEC, int NJ, bool PAGED>
+__global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
+    const float* __restrict__ probs, const void* __restrict__ src, const int* __restrict__ lengths,
+    float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct) {
+    using V = typename VecT<VEC>::type;
+    constexpr int kSliceV = kWave * NJ;          // V-elements per d-slice
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* p_sh = reinterpret_cast<float*>(smem_raw);                                   // ct floats
+    const float** ptr_sh = reinterpret_cast<const float**>(smem_raw + (size_t)ct * 4);  // ct/16 pointers
+    V* red = reinterpret_cast<V*>(smem_raw + (size_t)ct * 4 + (size_t)(ct / kPage) * 8);  // [waves][kSliceV]
+
+    const int b = blockIdx.y;
+    const int c = blockIdx.x;
+    const int L = min(lengths[b], S);
+    const int s0 = c * ct;
+    const int Dv = D / VEC;
+    const int v0 = blockIdx.z * kSliceV;         // first V-element of this slice
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+
+    if (s0 >= L) {
+        // an empty row still owes zeros to attention_result (reference softmax_v: result = 0)
+        if (direct && c == 0) {
+            V* o = reinterpret_cast<V*>(dst + (int64_t)b * D);
+            for (int i = threadIdx.x; i < kSliceV; i += kScanThreads)
+                if (v0 + i < Dv) o[v0 + i] = vzero<VEC>();
+        }
+        return;
+    }
+    const int s1 = min(s0 + ct, L);
+    const int ntok = s1 - s0;
+    for (int i = threadIdx.x; i < ntok; i += kScanThreads) p_sh[i] = probs[(int64_t)b * S + s0 + i];
+    if (PAGED) {
+        const float* const* pt = reinterpret_cast<const float* const*>(src);
+        const int npages = (ntok + kPage - 1) / kPage;
+        for (int i = threadIdx.x; i < npages; i += kScanThreads)
+            ptr_sh[i] = pt[(int64_t)b * (S / kPage) + s0 / kPage + i];
+    }
+    __syncthreads();
+
+    V acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = vzero<VEC>();
+    bool live[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) live[j] = (v0 + lane + j * kWave) < Dv;
+
+    const int ngroups = (ntok + kPage - 1) / kPage;  // 16-token groups (pages when PAGED)
+    for (int g = wave; g < ngroups; g += kScanWaves) {
+        const V* row0;
+        int64_t stride;  // in V units between consecutive tokens
+        if (PAGED) {
+            row0 = reinterpret_cast<const V*>(ptr_sh[g] + 2 * (int64_t)D);
+            stride = 3 * (int64_t)Dv;
+        } else {
+            row0 = reinterpret_cast<const V*>(reinterpret_cast<const float*>(src) +
+                                              ((int64_t)b * S + s0 + g * kPage) * D);
+            stride = Dv;
+        }
+        row0 += v0 + lane;
+        const int nt = min(kPage, ntok - g * kPage);
+        const float* pg = p_sh + g * kPage;
+        if (nt == kPage) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                V vb[8][NJ];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (live[j]) vb[t][j] = row0[(int64_t)(h * 8 + t) * stride + j * kWave];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float p = pg[h * 8 + t];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (live[j]) vfma<VEC>(p, vb[t][j], acc[j]);
+                }
+            }
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                const float p = pg[t];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (live[j]) vfma<VEC>(p, row0[(int64_t)t * stride + j * kWave], acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) red[wave * kSliceV + lane + j * kWave] = acc[j];
+    __syncthreads();
+    V* o = direct ? reinterpret_cast<V*>(dst + (int64_t)b * D)
+                  : reinterpret_cast<V*>(dst + ((int64_t)b * nchunk_max + c) * D);
+    for (int i = threadIdx.x; i < kSliceV; i += kScanThreads) {
+        if (v0 + i < Dv) {
+            V r = red[i];
+#pragma unroll
+            for (int w = 1; w < kScanWaves; ++w) vadd<VEC>(r, red[w * kSliceV + i]);
+            o[v0 + i] = r;
+        }
+    }
+}
+
+// attention_result[b, :] = sum over the row's chunks, in chunk order.  grid = (ceil(D/256), B).
+__global__ __launch_bounds__(kScanThreads) void softmax_v_combine_kernel(
+    const float* __restrict__ partial, const int* __restrict__ lengths, float* __restrict__ out,
+    int S, int D, int ct, int nchunk_max) {
+    const int b = blockIdx.y;
+    const int d = blockIdx.x * kScanThreads + threadIdx.x;
+    if (d >= D) return;
+    const int L = min(lengths[b], S);
+    const int nc = (L + ct - 1) / ct;
+    const float* p = partial + (int64_t)b * nchunk_max * D + d;
+    float r = 0.f;
+    for (int c = 0; c < nc; ++c) r += p[(int64_t)c * D];
+    out[(int64_t)b * D + d] = r;
+}
+
+__global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4* __restrict__ src,
+                                                                   float4* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kScanThreads;
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------
+template <int VEC, bool PAGED>
+static int launch_softmax_v_impl(const float* probs, const void* src, const int* lengths, float* out,
+                                 int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
+    const int Dv = D / VEC;
+    const int nj = min(4, ceil_div_i(Dv, kWave));
+    const int slice_v = kWave * nj;
+    const int nslices = ceil_div_i(Dv, slice_v);
+    int ct = pick_chunk_tokens(B, S);
+    const int nchunk = ceil_div_i(S, ct);
+    const int direct = nchunk == 1;
+    float* dst = out;
+    if (!direct) {
+        const size_t need = (size_t)B * nchunk * D * sizeof(float);
+        if (workspace == nullptr || ws_bytes < need) return MLI_ERR_WORKSPACE;
+        dst = reinterpret_cast<float*>(workspace);
+    }
+    const size_t smem = (size_t)ct * 4 + (size_t)(ct / kPage) * 8 + (size_t)kScanWaves * slice_v * VEC * 4;
+    dim3 grid(nchunk, B, nslices);
+#define MLI_SV_LAUNCH(NJ)                                                                         \
+    hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED>), grid, dim3(kScanThreads), smem, st, \
+                       probs, src, lengths, dst, S, D, ct, nchunk, direct)
+    switch (nj) {
+        case 1: MLI_SV_LAUNCH(1); break;
+        case 2: MLI_SV_LAUNCH(2); break;
+        case 3: MLI_SV_LAUNCH(3); break;
+        default: MLI_SV_LAUNCH(4); break;
+    }
+#undef MLI_SV_LAUNCH
+    int rc = launch_status();
+    if (rc || direct) return rc;
+    hipLaunchKernelGGL(softmax_v_combine_kernel, dim3(ceil_div_i(D, kScanThreads), B), dim3(kScanThreads), 0, st,
+                       reinterpret_cast<const float*>(workspace), lengths, out, S, D, ct, nchunk);
+    return launch_status();
+}
+
+int launch_qkt_paged(const float* q, const float* const* page_table, const int* lengths, float* qkt,
+                     int B, int S, int D, hipStream_t st) {
+    if (S % kPage != 0 || D % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
+    const int ct = pick_chunk_tokens(B, S);
+    const size_t smem = (size_t)D * 4 + (size_t)(ct / kPage) * 8;
+    hipLaunchKernelGGL(qkt_paged_kernel, dim3(ceil_div_i(S, ct), B), dim3(kScanThreads), smem, st,
+                       q, page_table, lengths, qkt, S, D, ct);
+    return launch_status();
+}
+
+int launch_qkt_naive(const float* q, const float* kt, const int* lengths, float* qkt, int B, int S, int D,
+                     hipStream_t st) {
+    if (S % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(qkt_naive_kernel, dim3(ceil_div_i(S, 256), B), dim3(kScanThreads),
+                       sizeof(float4) * kScanWaves * kWave + (size_t)D * 4, st, q, kt, lengths, qkt, S, D);
+    return launch_status();
+}
+
+int launch_softmax(float* qkt, const int* lengths, int B, int S, hipStream_t st) {
+    if (S % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(softmax_lengths_kernel, dim3(ceil_div_i(B, kScanWaves)), dim3(kScanThreads), 0, st,
+                       qkt, lengths, B, S);
+    return launch_status();
+}
+
+int launch_softmax_v_naive(const float* probs, const float* v_cache, const int* lengths, float* out,
+                           int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (B <= 0 || S <= 0 || D <= 0) return MLI_ERR_BAD_ARG;
+    if (D % 4 == 0) return launch_softmax_v_impl<4, false>(probs, v_cache, lengths, out, B, S, D, ws, ws_bytes, st);
+    return launch_softmax_v_impl<1, false>(probs, v_cache, lengths, out, B, S, D, ws, ws_bytes, st);
+}
+
+int launch_softmax_v_paged(const float* probs, const float* const* page_table, const int* lengths, float* out,
+                           int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (S % kPage != 0 || D % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
+    return launch_softmax_v_impl<4, true>(probs, page_table, lengths, out, B, S, D, ws, ws_bytes, st);
+}
+
+}  // namespace mli
+
+extern "C" {
+
+size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim) {
+    if (n_batch <= 0 || n_sequence <= 0 || dim <= 0) return 0;
+    // sized for the smallest chunk the heuristic (or MLI_CHUNK_TOKENS) may choose
+    const size_t nchunk = (size_t)mli::ceil_div_i(n_sequence, mli::kMinChunkTokens);
+    if (nchunk <= 1) return 0;
+    return (size_t)n_batch * nchunk * (size_t)dim * sizeof(float);
+}
+
+int mli_qkt(const float* q_output, const float* kt_cache, const int* lengths, float* qkt_output,
+            int n_batch, int n_sequence, int dim, void* stream) {
+    return mli::launch_qkt_naive(q_output, kt_cache, lengths, qkt_output, n_batch, n_sequence, dim,
+                                 mli::as_stream(stream));
+}
+
+int mli_softmax_in_place_with_lengths(float* qkt_output, const int* lengths, int n_batch, int n_sequence,
+                                      void* stream) {
+    return mli::launch_softmax(qkt_output, lengths, n_batch, n_sequence, mli::as_stream(stream));
+}
+
+int mli_softmax_v(const float* softmax_result, const float* v_cache, const int* lengths, float* attention_result,
+                  int n_batch, int n_sequence, int output_dim, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    return mli::launch_softmax_v_naive(softmax_result, v_cache, lengths, attention_result, n_batch, n_sequence,
+                                       output_dim, workspace, workspace_bytes, mli::as_stream(stream));
+}
+
+int mli_qkt_paged(const float* q_output, const float* const* page_table, const int* lengths, float* qkt_output,
+                  int n_batch, int n_sequence, int emb_dim, void* stream) {
+    return mli::launch_qkt_paged(q_output, page_table, lengths, qkt_output, n_batch, n_sequence, emb_dim,
+                                 mli::as_stream(stream));
+}
+
+int mli_softmax_v_paged(const float* softmax_result, const float* const* page_table, const int* lengths,
+                        float* attention_result, int n_batch, int n_sequence, int emb_dim, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    return mli::launch_softmax_v_paged(softmax_result, page_table, lengths, attention_result, n_batch, n_sequence,
+                                       emb_dim, workspace, workspace_bytes, mli::as_stream(stream));
+}
+
+int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream) {
+    if (n_floats % 4 != 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mli::stream_copy_kernel, dim3(256 * 16), dim3(mli::kScanThreads), 0, mli::as_stream(stream),
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n_floats / 4);
+    return mli::launch_status();
+}
+
+}  // extern "C"

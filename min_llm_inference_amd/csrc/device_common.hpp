@@ -1,0 +1,93 @@
+// Shared device-side helpers for the gfx950 kernels. Wavefront width is 64 everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mli_kernels.h"
+
+namespace mli {
+
+constexpr int kWave = 64;
+constexpr int kPage = MLI_PAGE_BLOCK_SIZE;   // tokens per page block (reference include/constants.h:12)
+constexpr int kSegInp = 0;                   // reference include/constants.h:16-18
+constexpr int kSegK = 1;
+constexpr int kSegV = 2;
+
+// float offset of (token slot, segment) inside one page block (reference include/utils.h:37,43)
+__device__ __forceinline__ int64_t page_row_offset(int i_sequence, int emb_dim, int seg) {
+    return (int64_t)(i_sequence % kPage) * emb_dim * 3 + (int64_t)seg * emb_dim;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ void axpy4(float p, const float4& v, float4& acc) {
+    acc.x = fmaf(p, v.x, acc.x);
+    acc.y = fmaf(p, v.y, acc.y);
+    acc.z = fmaf(p, v.z, acc.z);
+    acc.w = fmaf(p, v.w, acc.w);
+}
+
+// Sum 16 per-lane partials (one per token of a page) across the 64 lanes of a wave.
+// Transposing butterfly: 15 exchanges halve the live values at each of the first four
+// steps, two more finish the quad.  On return every lane holds the full sum for token
+// (lane >> 2) & 15.
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float send = b5 ? v[i] : v[i + 8];
+        float keep = b5 ? v[i + 8] : v[i];
+        a[i] = keep + __shfl_xor(send, 32, kWave);
+    }
+    float b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float send = b4 ? a[i] : a[i + 4];
+        float keep = b4 ? a[i + 4] : a[i];
+        b[i] = keep + __shfl_xor(send, 16, kWave);
+    }
+    float c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float send = b3 ? b[i] : b[i + 2];
+        float keep = b3 ? b[i + 2] : b[i];
+        c[i] = keep + __shfl_xor(send, 8, kWave);
+    }
+    float send = b2 ? c[0] : c[1];
+    float keep = b2 ? c[1] : c[0];
+    float d = keep + __shfl_xor(send, 4, kWave);
+    d += __shfl_xor(d, 2, kWave);
+    d += __shfl_xor(d, 1, kWave);
+    return d;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+inline int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mli

@@ -1,0 +1,197 @@
+// Token embedding for newly inserted rows and the greedy decoder head, plus the
+// contiguous->paged cloning helper the parity tests use.  Reference behaviour:
+//   src/kernels/encoder.cu:56-147  (inference_optimized_encoder, paged_attention_encoder)
+//   src/kernels/decoder.cu:25-255  (decoder_kernel, paged_attention_decoder_kernel_with_multi_decoder)
+//   src/kernels/utils.cu:106-160   (clone_inp_embedding_k_v_cache)
+#include <cfloat>
+
+#include "device_common.hpp"
+
+namespace mli {
+
+int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int K, hipStream_t st);
+
+constexpr int kEdThreads = 256;
+
+// One workgroup per (16-token group, new row); one wave per token, lanes along the embedding.
+template <bool PAGED>
+__global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
+    const float* __restrict__ emb_table, const float* __restrict__ wpe, const int* __restrict__ inp,
+    float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const int* __restrict__ lengths,
+    const int* __restrict__ new_item_indices, int S, int D) {
+    __shared__ float* page_sh;
+    const int b = new_item_indices[blockIdx.y];
+    const int L = lengths[b];
+    const int s_base = blockIdx.x * kPage;
+    if (s_base >= L) return;
+    if (PAGED) {
+        if (threadIdx.x == 0) page_sh = page_table[(int64_t)b * (S / kPage) + blockIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int D4 = D >> 2;
+    for (int t = wave; t < kPage; t += kEdThreads / kWave) {
+        const int s = s_base + t;
+        if (s >= L) break;
+        const int tok = inp[(int64_t)b * S + s];
+        const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
+        const float4* p = reinterpret_cast<const float4*>(wpe + (int64_t)s * D);
+        float* dst = PAGED ? page_sh + page_row_offset(s, D, kSegInp)
+                           : inp_embedding + ((int64_t)b * S + s) * D;
+        float4* o = reinterpret_cast<float4*>(dst);
+        for (int i = lane; i < D4; i += kWave) {
+            const float4 a = e[i], c = p[i];
+            o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        }
+    }
+}
+
+// One workgroup per batch row.  argmax keeps the LOWEST index among equal maxima (the reference's
+// host decoder, tests/test_utils.cpp:607-614; its device kernel breaks ties by thread order).
+template <bool PAGED>
+__global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
+    const float* __restrict__ emb_score, int* __restrict__ decoder_result, int* __restrict__ lengths,
+    float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const float* __restrict__ wpe_table,
+    const float* __restrict__ emb_table, int n_vocab, int S, int D, int n_decoder_results, int i_decoder) {
+    __shared__ float best_v[kEdThreads / kWave];
+    __shared__ int best_i[kEdThreads / kWave];
+    __shared__ int tok_sh;
+    __shared__ float* page_sh;
+    const int b = blockIdx.x;
+    const int L = lengths[b];
+    if (L == 0) {  // empty slot
+        if (threadIdx.x == 0) decoder_result[(int64_t)b * n_decoder_results + i_decoder] = MLI_EMPTY_ROW_TOKEN_ID;
+        return;
+    }
+    const float* sc = emb_score + (int64_t)b * n_vocab;
+    float mv = -FLT_MAX;
+    int mi = -1;
+    for (int i = threadIdx.x; i < n_vocab; i += kEdThreads) {
+        const float v = sc[i];
+        if (v > mv) { mv = v; mi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(mv, off, kWave);
+        const int oi = __shfl_xor(mi, off, kWave);
+        if (ov > mv || (ov == mv && (unsigned)oi < (unsigned)mi)) { mv = ov; mi = oi; }
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) { best_v[wave] = mv; best_i[wave] = mi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = best_v[0];
+        int bi = best_i[0];
+        for (int w = 1; w < kEdThreads / kWave; ++w)
+            if (best_v[w] > bv || (best_v[w] == bv && (unsigned)best_i[w] < (unsigned)bi)) { bv = best_v[w]; bi = best_i[w]; }
+        tok_sh = bi;
+        decoder_result[(int64_t)b * n_decoder_results + i_decoder] = bi;
+        const bool done = (L + 1 >= S) || bi == MLI_EOF_TOKEN_ID;
+        lengths[b] = done ? 0 : L + 1;
+        if (PAGED && !done) page_sh = page_table[(int64_t)b * (S / kPage) + L / kPage];
+    }
+    __syncthreads();
+    const int tok = tok_sh;
+    if (L + 1 >= S || tok == MLI_EOF_TOKEN_ID || tok < 0) return;  // finished rows get no next embedding
+    const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
+    const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
+    float* dst = PAGED ? page_sh + page_row_offset(L, D, kSegInp) : inp_embedding + ((int64_t)b * S + L) * D;
+    float4* o = reinterpret_cast<float4*>(dst);
+    for (int i = threadIdx.x; i < (D >> 2); i += kEdThreads) {
+        const float4 a = e[i], c = p[i];
+        o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+}
+
+// grid = (S/16, B).  Positions 0..min(L, S-1) inclusive are cloned (the decoder writes the next
+// position's embedding, so one more than the length is materialised; reference utils.cu:125-127).
+__global__ __launch_bounds__(kEdThreads) void clone_to_pages_kernel(
+    float* const* __restrict__ page_table, const float* __restrict__ inp_embedding,
+    const float* __restrict__ kt_cache, const float* __restrict__ v_cache, const int* __restrict__ lengths,
+    int S, int D) {
+    const int b = blockIdx.y;
+    const int L = lengths[b];
+    if (L == 0) return;  // never allocated
+    const int last = min(L, S - 1);
+    const int s_base = blockIdx.x * kPage;
+    if (s_base > last) return;
+    float* page = page_table[(int64_t)b * (S / kPage) + blockIdx.x];
+    for (int idx = threadIdx.x; idx < kPage * D; idx += kEdThreads) {
+        const int t = idx / D, d = idx % D;
+        const int s = s_base + t;
+        if (s > last) continue;
+        float* row = page + (int64_t)t * 3 * D;
+        row[d] = inp_embedding[((int64_t)b * S + s) * D + d];
+        row[D + d] = kt_cache[((int64_t)b * D + d) * S + s];
+        row[2 * D + d] = v_cache[((int64_t)b * S + s) * D + d];
+    }
+}
+
+}  // namespace mli
+
+extern "C" {
+
+int mli_inference_optimized_encoder(const float* emb_table, const float* wpe, const int* inp, float* inp_embedding,
+                                    const int* lengths, const int* new_item_indices, int n_batch, int n_sequence,
+                                    int emb_dim, int n_new_items, void* stream) {
+    if (n_new_items == 0) return 0;  // reference encoder.cu:84-86
+    if (n_new_items < 0 || emb_dim % 4 != 0 || n_batch <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL((mli::encoder_new_rows_kernel<false>), dim3(mli::ceil_div_i(n_sequence, mli::kPage), n_new_items),
+                       dim3(mli::kEdThreads), 0, mli::as_stream(stream), emb_table, wpe, inp, inp_embedding,
+                       (float* const*)nullptr, lengths, new_item_indices, n_sequence, emb_dim);
+    return mli::launch_status();
+}
+
+int mli_paged_attention_encoder(const float* emb_table, const float* wpe, const int* inp, float* const* page_table,
+                                const int* lengths, const int* new_item_indices, int n_batch, int n_sequence,
+                                int emb_dim, int n_new_items, void* stream) {
+    if (n_new_items == 0) return 0;  // reference encoder.cu:138-140
+    if (n_new_items < 0 || emb_dim % 4 != 0 || n_sequence % mli::kPage != 0 || n_batch <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL((mli::encoder_new_rows_kernel<true>), dim3(n_sequence / mli::kPage, n_new_items),
+                       dim3(mli::kEdThreads), 0, mli::as_stream(stream), emb_table, wpe, inp, (float*)nullptr,
+                       page_table, lengths, new_item_indices, n_sequence, emb_dim);
+    return mli::launch_status();
+}
+
+int mli_decoder(const float* batch_result, const float* emb_table, float* emb_score, const float* wpe_table,
+                float* inp_embedding, int* lengths, int* decoder_result, int n_batch, int n_vocab, int n_sequence,
+                int emb_dim, void* stream) {
+    if (emb_dim % 4 != 0 || n_batch <= 0 || n_vocab <= 0) return MLI_ERR_BAD_ARG;
+    hipStream_t st = mli::as_stream(stream);
+    int rc = mli::launch_gemm_nt(batch_result, emb_table, emb_score, n_batch, n_vocab, emb_dim, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mli::decoder_argmax_kernel<false>), dim3(n_batch), dim3(mli::kEdThreads), 0, st, emb_score,
+                       decoder_result, lengths, inp_embedding, (float* const*)nullptr, wpe_table, emb_table, n_vocab,
+                       n_sequence, emb_dim, 1, 0);
+    return mli::launch_status();
+}
+
+int mli_paged_decoder_multi_rounds(const float* batch_result, const float* emb_table, float* emb_score,
+                                   const float* wpe_table, float* const* page_table, int* lengths,
+                                   int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                                   int n_decoder_results, int i_decoder, void* stream) {
+    if (emb_dim % 4 != 0 || n_sequence % mli::kPage != 0 || n_batch <= 0 || n_vocab <= 0 || n_decoder_results <= 0 ||
+        i_decoder < 0 || i_decoder >= n_decoder_results)
+        return MLI_ERR_BAD_ARG;
+    hipStream_t st = mli::as_stream(stream);
+    int rc = mli::launch_gemm_nt(batch_result, emb_table, emb_score, n_batch, n_vocab, emb_dim, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mli::decoder_argmax_kernel<true>), dim3(n_batch), dim3(mli::kEdThreads), 0, st, emb_score,
+                       decoder_result, lengths, (float*)nullptr, page_table, wpe_table, emb_table, n_vocab,
+                       n_sequence, emb_dim, n_decoder_results, i_decoder);
+    return mli::launch_status();
+}
+
+int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp_embedding, const float* kt_cache,
+                                      const float* v_cache, const int* lengths, int n_batch, int n_sequence,
+                                      int emb_dim, void* stream) {
+    if (n_sequence % mli::kPage != 0 || n_batch <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mli::clone_to_pages_kernel, dim3(n_sequence / mli::kPage, n_batch), dim3(mli::kEdThreads), 0,
+                       mli::as_stream(stream), page_table, inp_embedding, kt_cache, v_cache, lengths, n_sequence,
+                       emb_dim);
+    return mli::launch_status();
+}
+
+}  // extern "C"

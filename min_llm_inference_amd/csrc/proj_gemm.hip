@@ -1,0 +1,384 @@
+// fp32 MFMA GEMM core for every dense product on the decode path:
+//   * decode projection   x[B,D] . [Wk|Wq|Wv]   with gather prologue + page/cache scatter epilogue
+//       replaces get_latest_kt_q_v                  (src/kernels/self_attention_inference_optimized.cu:100-143)
+//                get_latest_k_q_v_paged_attention   (src/kernels/paged_attention.cu:126-180)
+//                get_latest_batch_embs + 3 x cublasSgemm + save_to_page_table
+//                                                   (src/kernels/paged_attention_cublas.cu:16-99)
+//   * prefill fill        X_b[L_b,D] . [Wk|Wv]  for newly inserted rows
+//       replaces fill_new_kt_v_cache                (…optimized.cu:27-85)
+//                fill_new_k_v_cache_paged_attention (paged_attention.cu:20-87)
+//                fill_new_k_v_cache_paged_attention_warp_tiling (paged_attention_cublas.cu:112-223)
+//   * decoder logits      attn[B,D] . emb_table[V,D]^T
+//       replaces gemm_transpose_kernel (src/kernels/gemm.cu:13-51) / cublasSgemm (src/kernels/decoder.cu:247-249)
+//
+// v_mfma_f32_32x32x2_f32 is an exact, k-ordered fp32 fma chain, so results are fp32-faithful
+// (no TF32-style truncation).  Tile: 64x64x32 per 256-thread workgroup, 2x2 waves of 32x32.
+// Per-row source / destination pointers are resolved once per workgroup into LDS (this is where
+// the page table is read: one pointer per row, never inside the k loop).
+#include "device_common.hpp"
+
+namespace mli {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDA = BM + 1;   // k-major LDS tiles written transposed with b32 stores: +1 is conflict-free
+constexpr int LDB = BN + 4;   // [k][n] tile written with b128 stores: rows stay 16-byte aligned
+constexpr int LDBT = BN + 1;  // [n][k] source (transposed B): same treatment as A
+constexpr int kGemmThreads = 256;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum GemmMode : int {
+    kNaiveLatest = 0,
+    kNaiveFill = 1,
+    kPagedLatest = 2,
+    kPagedFill = 3,
+    kPlain = 4,  // C[M,N] = A[M,K] . B  (B is [K,N], or [N,K] when b_transposed)
+};
+
+struct GemmArgs {
+    // weights / B operands: up to three [K, N] matrices (k, q, v) -- or one [N, K] matrix (plain, transposed)
+    const float* w[3];
+    int n_out;       // how many of w[] are live
+    int out_id[3];   // which output each live weight feeds: 0 = K, 1 = Q, 2 = V
+    int M, N, K;     // M = rows per z-slice upper bound, N = out dim, K = in dim
+    // row sources / sinks
+    const float* a_plain;  // kPlain: A
+    float* c_plain;        // kPlain: C
+    int lda, ldc;
+    const float* inp_embedding;  // naive: [B, S, K]
+    float* kt_cache;             // naive: [B, N, S]
+    float* v_cache;              // naive: [B, S, N]
+    float* const* page_table;    // paged: [B, S/16]
+    float* q_output;             // latest: [B, N]
+    const int* lengths;
+    const int* new_batch_idx;    // fill
+    int B, S;
+};
+
+struct RowDesc {
+    const float* a;  // nullptr -> row contributes zeros and is not stored
+    float* o;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
+    RowDesc r{nullptr, nullptr};
+    if (MODE == kPlain) {
+        if (m < g.M) {
+            r.a = g.a_plain + (int64_t)m * g.lda;
+            r.o = g.c_plain + (int64_t)m * g.ldc;
+        }
+        return r;
+    }
+    int b, s;
+    if (MODE == kNaiveLatest || MODE == kPagedLatest) {
+        b = m;
+        if (b >= g.B) return r;
+        const int L = g.lengths[b];
+        if (L <= 0) return r;  // empty slot: nothing read, nothing written
+        s = L - 1;
+    } else {
+        b = g.new_batch_idx[z];
+        s = m;
+        if (s >= g.lengths[b]) return r;
+    }
+    if (MODE == kNaiveLatest || MODE == kNaiveFill) {
+        r.a = g.inp_embedding + ((int64_t)b * g.S + s) * g.K;
+        if (out_id == 0) {  // K is kept transposed: kt_cache[b, n, s]
+            r.o = g.kt_cache + (int64_t)b * g.N * g.S + s;
+        } else if (out_id == 1) {
+            r.o = g.q_output + (int64_t)b * g.N;
+        } else {
+            r.o = g.v_cache + ((int64_t)b * g.S + s) * g.N;
+        }
+    } else {
+        float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
+        float* tok = page + page_row_offset(s, g.K, kSegInp);
+        r.a = tok;
+        if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;
+        else r.o = tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;
+    }
+    return r;
+}
+
+// VEC4: K % 4 == 0, N % 4 == 0 and 16-byte aligned rows -> float4 global loads.
+template <int MODE, bool BT, bool VEC4>
+__global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
+    __shared__ float As[BK * LDA];
+    constexpr int LDBX = BT ? LDBT : LDB;
+    __shared__ __align__(16) float Bs[BK * LDBX];
+    __shared__ const float* a_ptr[BM];
+    __shared__ float* o_ptr[BM];
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int wsel = blockIdx.x / tiles_n;
+    const int n0 = (blockIdx.x % tiles_n) * BN;
+    const int m0 = blockIdx.y * BM;
+    const int z = blockIdx.z;
+    const int out_id = g.out_id[wsel];
+    const float* __restrict__ Bmat = g.w[wsel];
+
+    if (MODE == kNaiveFill || MODE == kPagedFill) {
+        // whole tile beyond the row's length: nothing to do (reference …optimized.cu:43-45)
+        if (m0 >= g.lengths[g.new_batch_idx[z]]) return;
+    }
+
+    const int tid = threadIdx.x;
+    if (tid < BM) {
+        RowDesc r = resolve_row<MODE>(g, m0 + tid, z, out_id);
+        a_ptr[tid] = r.a;
+        o_ptr[tid] = r.o;
+    }
+    // only the contiguous layout keeps K transposed (kt_cache[b, n, s]): element stride S along n
+    constexpr bool kCanTranspose = MODE == kNaiveLatest || MODE == kNaiveFill;
+    const bool transposed_out = kCanTranspose && out_id == 0;
+    const int64_t o_stride = transposed_out ? g.S : 1;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave >> 1) * 32;
+    const int wn = (wave & 1) * 32;
+
+    // global -> register staging coordinates
+    //   A tile [BM][BK]: 8 threads per row (float4 along k), 32 rows per pass, 2 passes
+    //   B tile [BK][BN]: 16 threads per k-row (float4 along n), 16 k-rows per pass, 2 passes
+    //   B^T tile (BT): rows are n, float4 along k -- same shape as the A tile
+    const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
+    const int b_row = tid >> 4, b_nq = (tid & 15) * 4;
+    float4 a_reg[2], b_reg[2];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* ap = a_ptr[a_row + p * 32];
+            const int k = k0 + a_kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ap != nullptr) {
+                if (VEC4) {
+                    if (k < g.K) v = *reinterpret_cast<const float4*>(ap + k);
+                } else {
+                    if (k + 0 < g.K) v.x = ap[k + 0];
+                    if (k + 1 < g.K) v.y = ap[k + 1];
+                    if (k + 2 < g.K) v.z = ap[k + 2];
+                    if (k + 3 < g.K) v.w = ap[k + 3];
+                }
+            }
+            a_reg[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BT) {
+                const int n = n0 + a_row + p * 32;
+                const int k = k0 + a_kq;
+                if (n < g.N) {
+                    const float* bp = Bmat + (int64_t)n * g.K + k;
+                    if (VEC4) {
+                        if (k < g.K) v = *reinterpret_cast<const float4*>(bp);
+                    } else {
+                        if (k + 0 < g.K) v.x = bp[0];
+                        if (k + 1 < g.K) v.y = bp[1];
+                        if (k + 2 < g.K) v.z = bp[2];
+                        if (k + 3 < g.K) v.w = bp[3];
+                    }
+                }
+            } else {
+                const int k = k0 + b_row + p * 16;
+                const int n = n0 + b_nq;
+                if (k < g.K) {
+                    const float* bp = Bmat + (int64_t)k * g.N + n;
+                    if (VEC4) {
+                        if (n < g.N) v = *reinterpret_cast<const float4*>(bp);
+                    } else {
+                        if (n + 0 < g.N) v.x = bp[0];
+                        if (n + 1 < g.N) v.y = bp[1];
+                        if (n + 2 < g.N) v.z = bp[2];
+                        if (n + 3 < g.N) v.w = bp[3];
+                    }
+                }
+            }
+            b_reg[p] = v;
+        }
+    };
+
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int m = a_row + p * 32;
+            As[(a_kq + 0) * LDA + m] = a_reg[p].x;
+            As[(a_kq + 1) * LDA + m] = a_reg[p].y;
+            As[(a_kq + 2) * LDA + m] = a_reg[p].z;
+            As[(a_kq + 3) * LDA + m] = a_reg[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (BT) {
+                const int n = a_row + p * 32;
+                Bs[(a_kq + 0) * LDBX + n] = b_reg[p].x;
+                Bs[(a_kq + 1) * LDBX + n] = b_reg[p].y;
+                Bs[(a_kq + 2) * LDBX + n] = b_reg[p].z;
+                Bs[(a_kq + 3) * LDBX + n] = b_reg[p].w;
+            } else {
+                *reinterpret_cast<float4*>(&Bs[(b_row + p * 16) * LDBX + b_nq]) = b_reg[p];
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    const int lk = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
+    const int li = lane & 31;   // row (A) / column (B) inside the 32x32 wave tile
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load_tile((t + 1) * BK);  // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[(kk + lk) * LDA + wm + li];
+            const float b = Bs[(kk + lk) * LDBX + wn + li];
+            // the K output of the contiguous layout is stored transposed: swap operands so
+            // that the sequence index lands on the lane (coalesced kt_cache stores)
+            if (transposed_out) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: accumulator register r of lane l is tile element
+    //   (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (transposed_out) {
+            const int n = n0 + wn + trow;   // rows of the swapped product run along N
+            const int mi = wm + li;
+            float* op = o_ptr[mi];
+            if (op != nullptr && n < g.N) op[(int64_t)n * o_stride] = acc[r];
+        } else {
+            const int mi = wm + trow;
+            const int n = n0 + wn + li;
+            float* op = o_ptr[mi];
+            if (op != nullptr && n < g.N) op[n] = acc[r];
+        }
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int MODE, bool BT>
+static int launch_gemm(const GemmArgs& g, int m_tiles, int z, bool vec4, hipStream_t st) {
+    if (g.N <= 0 || g.K <= 0 || m_tiles <= 0 || z <= 0) return MLI_ERR_BAD_ARG;
+    dim3 grid(ceil_div_i(g.N, BN) * g.n_out, m_tiles, z);
+    if (vec4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true>), grid, dim3(kGemmThreads), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, false>), grid, dim3(kGemmThreads), 0, st, g);
+    return launch_status();
+}
+
+int launch_latest_naive(const float* inp, const int* lengths, const float* wk, const float* wq, const float* wv,
+                        float* kt, float* v, float* q, int B, int S, int Din, int Dout, hipStream_t st) {
+    if (B <= 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = wk; g.w[1] = wq; g.w[2] = wv; g.n_out = 3;
+    g.out_id[0] = 0; g.out_id[1] = 1; g.out_id[2] = 2;
+    g.M = B; g.N = Dout; g.K = Din;
+    g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.q_output = q; g.lengths = lengths;
+    g.B = B; g.S = S;
+    const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wq) && aligned16(wv);
+    return launch_gemm<kNaiveLatest, false>(g, ceil_div_i(B, BM), 1, vec4, st);
+}
+
+int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, const float* wk, const float* wv,
+                      float* kt, float* v, int B, int S, int Din, int Dout, int n_new, hipStream_t st) {
+    if (n_new == 0) return 0;  // reference …optimized.cu:308-310
+    if (n_new < 0 || B <= 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = wk; g.w[1] = wv; g.n_out = 2;
+    g.out_id[0] = 0; g.out_id[1] = 2;
+    g.M = S; g.N = Dout; g.K = Din;
+    g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.lengths = lengths; g.new_batch_idx = new_idx;
+    g.B = B; g.S = S;
+    const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wv);
+    return launch_gemm<kNaiveFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
+}
+
+int launch_latest_paged(float* const* page_table, const int* lengths, const float* wk, const float* wq,
+                        const float* wv, float* q, int B, int S, int D, hipStream_t st) {
+    if (B <= 0 || S % kPage != 0 || D % 4 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = wk; g.w[1] = wq; g.w[2] = wv; g.n_out = 3;
+    g.out_id[0] = 0; g.out_id[1] = 1; g.out_id[2] = 2;
+    g.M = B; g.N = D; g.K = D;
+    g.page_table = page_table; g.q_output = q; g.lengths = lengths;
+    g.B = B; g.S = S;
+    const bool vec4 = aligned16(wk) && aligned16(wq) && aligned16(wv);
+    return launch_gemm<kPagedLatest, false>(g, ceil_div_i(B, BM), 1, vec4, st);
+}
+
+int launch_fill_paged(float* const* page_table, const int* new_idx, const int* lengths, const float* wk,
+                      const float* wv, int B, int S, int D, int n_new, hipStream_t st) {
+    if (n_new == 0) return 0;  // reference paged_attention.cu:100-102
+    if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 4 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = wk; g.w[1] = wv; g.n_out = 2;
+    g.out_id[0] = 0; g.out_id[1] = 2;
+    g.M = S; g.N = D; g.K = D;
+    g.page_table = page_table; g.lengths = lengths; g.new_batch_idx = new_idx;
+    g.B = B; g.S = S;
+    const bool vec4 = aligned16(wk) && aligned16(wv);
+    return launch_gemm<kPagedFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
+}
+
+// C[M, N] = A[M, K] . Bt[N, K]^T
+int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int K, hipStream_t st) {
+    if (M <= 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = Bt; g.n_out = 1; g.out_id[0] = 1;
+    g.M = M; g.N = N; g.K = K;
+    g.a_plain = A; g.c_plain = C; g.lda = K; g.ldc = N;
+    const bool vec4 = K % 4 == 0 && aligned16(A) && aligned16(Bt);
+    return launch_gemm<kPlain, true>(g, ceil_div_i(M, BM), 1, vec4, st);
+}
+
+}  // namespace mli
+
+extern "C" {
+
+int mli_fill_new_kt_v_cache(const float* inp_embedding, const int* new_batch_idx, const int* lengths,
+                            const float* wk, const float* wv, float* kt_cache, float* v_cache, int n_batch,
+                            int n_sequence, int input_dim, int output_dim, int n_new_items, void* stream) {
+    return mli::launch_fill_naive(inp_embedding, new_batch_idx, lengths, wk, wv, kt_cache, v_cache, n_batch,
+                                  n_sequence, input_dim, output_dim, n_new_items, mli::as_stream(stream));
+}
+
+int mli_get_latest_kt_q_v(const float* inp_embedding, const int* lengths, const float* wk, const float* wq,
+                          const float* wv, float* kt_cache, float* v_cache, float* q_output, int n_batch,
+                          int n_sequence, int input_dim, int output_dim, void* stream) {
+    return mli::launch_latest_naive(inp_embedding, lengths, wk, wq, wv, kt_cache, v_cache, q_output, n_batch,
+                                    n_sequence, input_dim, output_dim, mli::as_stream(stream));
+}
+
+int mli_fill_new_k_v_cache_paged(float* const* page_table, const int* new_batch_idx, const int* lengths,
+                                 const float* wk, const float* wv, int n_batch, int n_sequence, int emb_dim,
+                                 int n_new_items, void* stream) {
+    return mli::launch_fill_paged(page_table, new_batch_idx, lengths, wk, wv, n_batch, n_sequence, emb_dim,
+                                  n_new_items, mli::as_stream(stream));
+}
+
+int mli_get_latest_k_q_v_paged(float* const* page_table, const int* lengths, const float* wk, const float* wq,
+                               const float* wv, float* q_output, int n_batch, int n_sequence, int emb_dim,
+                               void* stream) {
+    return mli::launch_latest_paged(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim,
+                                    mli::as_stream(stream));
+}
+
+}  // extern "C"

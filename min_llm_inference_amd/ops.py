@@ -1,0 +1,190 @@
+"""torch-tensor front end over the C ABI, one function per reference launcher (same names).
+
+torch supplies device memory and the stream only; every computation happens in libmli_hip.so.
+Argument order and meaning follow the reference headers
+(include/kernels/self_attention_inference_optimized.h, include/kernels/paged_attention.h,
+include/kernels/encoder.h, include/kernels/decoder.h); scalars the reference derives from
+Tensor shapes are derived from the torch shapes here in the same way.
+"""
+import ctypes
+
+import torch
+
+from ._lib import MliError, load_library
+
+PAGE_BLOCK_SIZE = 16
+EMPTY_ROW_TOKEN_ID = -1
+EOF_TOKEN_ID = 1023
+
+_workspaces = {}
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise MliError("libmli_hip.so operates on device tensors only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise MliError("tensors crossing the C ABI must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MliError(f"Hip Failure: {what} returned {rc}")
+
+
+def workspace_for(n_batch, n_sequence, dim, device):
+    """Caller-owned scratch for the split-sequence kernels (grown on demand, never inside a timed region)."""
+    lib = load_library()
+    need = int(lib.mli_attention_workspace_bytes(n_batch, n_sequence, dim))
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws, need
+
+
+# ---- contiguous ("naive") path ------------------------------------------------------------
+def launch_fill_new_kt_v_cache(inp_embedding, new_batch_idx, lengths, wk, wv, kt_cache, v_cache, n_new_items):
+    B, S, Din = inp_embedding.shape
+    _check(load_library().mli_fill_new_kt_v_cache(_p(inp_embedding), _p(new_batch_idx), _p(lengths), _p(wk), _p(wv),
+                                                  _p(kt_cache), _p(v_cache), B, S, Din, wk.shape[1], n_new_items,
+                                                  _stream()), "mli_fill_new_kt_v_cache")
+
+
+def launch_get_latest_kt_q_v(inp_embedding, lengths, wk, wq, wv, kt_cache, v_cache, q_output):
+    B, S, Din = inp_embedding.shape
+    _check(load_library().mli_get_latest_kt_q_v(_p(inp_embedding), _p(lengths), _p(wk), _p(wq), _p(wv), _p(kt_cache),
+                                                _p(v_cache), _p(q_output), B, S, Din, wk.shape[1], _stream()),
+           "mli_get_latest_kt_q_v")
+
+
+def launch_qkt(q_output, kt_cache, lengths, qkt_output):
+    B, D = q_output.shape
+    _check(load_library().mli_qkt(_p(q_output), _p(kt_cache), _p(lengths), _p(qkt_output), B, kt_cache.shape[2], D,
+                                  _stream()), "mli_qkt")
+
+
+def launch_softmax_in_place_with_lengths(qkt_output, lengths):
+    B, S = qkt_output.shape
+    _check(load_library().mli_softmax_in_place_with_lengths(_p(qkt_output), _p(lengths), B, S, _stream()),
+           "mli_softmax_in_place_with_lengths")
+
+
+def launch_softmax_v(softmax_result, v_cache, attention_result, lengths):
+    B, S, D = v_cache.shape
+    ws, need = workspace_for(B, S, D, v_cache.device)
+    _check(load_library().mli_softmax_v(_p(softmax_result), _p(v_cache), _p(lengths), _p(attention_result), B, S, D,
+                                        _p(ws), need, _stream()), "mli_softmax_v")
+
+
+def inference_self_attention(inp_embedding, lengths, wk, wq, wv, new_batch_idx, kt_cache, v_cache, q_output,
+                             qkt_output, attention_result, n_new_items):
+    B, S, Din = inp_embedding.shape
+    Dout = wk.shape[1]
+    ws, need = workspace_for(B, S, Dout, inp_embedding.device)
+    _check(load_library().mli_inference_self_attention(
+        _p(inp_embedding), _p(lengths), _p(wk), _p(wq), _p(wv), _p(new_batch_idx), _p(kt_cache), _p(v_cache),
+        _p(q_output), _p(qkt_output), _p(attention_result), B, S, Din, Dout, n_new_items, _p(ws), need, _stream()),
+        "mli_inference_self_attention")
+
+
+# ---- paged path (page_table: int64 [B, S/16] tensor of device addresses) -----------------------
+def launch_fill_new_k_v_cache_paged_attention(page_table, new_batch_idx, lengths, wk, wv, n_new_items, n_sequence):
+    B = page_table.shape[0]
+    _check(load_library().mli_fill_new_k_v_cache_paged(_p(page_table), _p(new_batch_idx), _p(lengths), _p(wk), _p(wv),
+                                                       B, n_sequence, wk.shape[0], n_new_items, _stream()),
+           "mli_fill_new_k_v_cache_paged")
+
+
+# the reference's warp-tiled variant is the same MFMA kernel here
+launch_fill_new_k_v_cache_paged_attention_warp_tiling = launch_fill_new_k_v_cache_paged_attention
+
+
+def launch_get_latest_k_q_v_paged_attention(page_table, lengths, wk, wq, wv, q_output, n_sequence):
+    B = page_table.shape[0]
+    _check(load_library().mli_get_latest_k_q_v_paged(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv),
+                                                     _p(q_output), B, n_sequence, wq.shape[0], _stream()),
+           "mli_get_latest_k_q_v_paged")
+
+
+def launch_qkt_paged_attention(q_output, page_table, lengths, qkt_output):
+    B, D = q_output.shape
+    _check(load_library().mli_qkt_paged(_p(q_output), _p(page_table), _p(lengths), _p(qkt_output), B,
+                                        qkt_output.shape[1], D, _stream()), "mli_qkt_paged")
+
+
+def launch_softmax_v_paged_attention(softmax_result, page_table, attention_result, lengths):
+    B, S = softmax_result.shape
+    D = attention_result.shape[1]
+    ws, need = workspace_for(B, S, D, softmax_result.device)
+    _check(load_library().mli_softmax_v_paged(_p(softmax_result), _p(page_table), _p(lengths), _p(attention_result),
+                                              B, S, D, _p(ws), need, _stream()), "mli_softmax_v_paged")
+
+
+def paged_attention(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qkt_output, attention_result,
+                    n_new_items, n_sequence):
+    B = page_table.shape[0]
+    D = wk.shape[0]
+    ws, need = workspace_for(B, n_sequence, D, q_output.device)
+    _check(load_library().mli_paged_attention(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv), _p(new_batch_idx),
+                                              _p(q_output), _p(qkt_output), _p(attention_result), B, n_sequence, D,
+                                              n_new_items, _p(ws), need, _stream()), "mli_paged_attention")
+
+
+paged_attention_with_cublas = paged_attention  # one gather-GEMM-scatter kernel replaces the cuBLAS trio
+
+
+# ---- encoder / decoder ---------------------------------------------------------------------
+def launch_inference_optimized_encoder_kernel(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices,
+                                              n_new_items):
+    B, S, D = inp_embedding.shape
+    _check(load_library().mli_inference_optimized_encoder(_p(emb_table), _p(wpe), _p(inp), _p(inp_embedding),
+                                                          _p(lengths), _p(new_item_indices), B, S, D, n_new_items,
+                                                          _stream()), "mli_inference_optimized_encoder")
+
+
+def launch_paged_attention_encoder_kernel(emb_table, wpe, inp, page_table, lengths, new_item_indices, n_new_items):
+    B, S = inp.shape
+    _check(load_library().mli_paged_attention_encoder(_p(emb_table), _p(wpe), _p(inp), _p(page_table), _p(lengths),
+                                                      _p(new_item_indices), B, S, emb_table.shape[1], n_new_items,
+                                                      _stream()), "mli_paged_attention_encoder")
+
+
+def launch_decoder(batch_result, emb_table, emb_score, wpe_table, inp_embedding, lengths, decoder_result):
+    B, D = batch_result.shape
+    _check(load_library().mli_decoder(_p(batch_result), _p(emb_table), _p(emb_score), _p(wpe_table),
+                                      _p(inp_embedding), _p(lengths), _p(decoder_result), B, emb_table.shape[0],
+                                      wpe_table.shape[0], D, _stream()), "mli_decoder")
+
+
+def launch_paged_attention_decoder_multi_rounds(batch_result, emb_table, emb_score, wpe_table, page_table, lengths,
+                                                decoder_result, i_decoder):
+    B, D = batch_result.shape
+    n_res = decoder_result.shape[1] if decoder_result.dim() == 2 else 1
+    _check(load_library().mli_paged_decoder_multi_rounds(_p(batch_result), _p(emb_table), _p(emb_score),
+                                                         _p(wpe_table), _p(page_table), _p(lengths),
+                                                         _p(decoder_result), B, emb_table.shape[0],
+                                                         wpe_table.shape[0], D, n_res, i_decoder, _stream()),
+           "mli_paged_decoder_multi_rounds")
+
+
+launch_paged_attention_cublas_decoder_multi_rounds = launch_paged_attention_decoder_multi_rounds
+
+
+# ---- test / measurement support -------------------------------------------------------------
+def launch_clone_inp_embedding_k_v_cache(page_table, inp_embedding, kt_cache, v_cache, lengths):
+    B, S, D = inp_embedding.shape
+    _check(load_library().mli_clone_inp_embedding_k_v_cache(_p(page_table), _p(inp_embedding), _p(kt_cache),
+                                                            _p(v_cache), _p(lengths), B, S, D, _stream()),
+           "mli_clone_inp_embedding_k_v_cache")
+
+
+def stream_copy(src, dst):
+    _check(load_library().mli_stream_copy(_p(src), _p(dst), src.numel(), _stream()), "mli_stream_copy")

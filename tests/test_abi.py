@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/mli_kernels.h (and include/mli_engine.h) declares, and the Python binding table matches the header.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"\b(mli_[a-z0-9_]+)\s*\(", text)
+
+
+def test_library_exports_every_declared_symbol(mli):
+    names = _declared("mli_kernels.h") + _declared("mli_engine.h")
+    assert len(set(names)) >= 19
+    for n in set(names):
+        assert hasattr(mli, n), f"libmli_hip.so does not export {n}"
+
+
+def test_binding_table_matches_header():
+    from min_llm_inference_amd import _lib
+    declared = set(_declared("mli_kernels.h"))
+    bound = {n for n in _lib.SIGNATURES if not n.startswith("mli_engine")}
+    assert declared == bound, (declared ^ bound)
+
+
+def test_arity_matches_header():
+    """Each binding passes exactly as many arguments as the C prototype takes."""
+    from min_llm_inference_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mli_kernels.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, args in re.findall(r"\b(mli_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        n = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        assert len(_lib.SIGNATURES[name]) == n, (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_abi_version_and_workspace_query(mli):
+    assert mli.mli_abi_version() == 1
+    assert mli.mli_attention_workspace_bytes(4, 64, 64) == 0           # single chunk: no scratch
+    assert mli.mli_attention_workspace_bytes(1024, 4096, 512) == 1024 * 64 * 512 * 4
+    assert mli.mli_attention_workspace_bytes(0, 4096, 512) == 0
+
+
+def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
+    from min_llm_inference_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "library_path", lambda: str(tmp_path / "nope.so"))
+    try:
+        _lib.load_library()
+    except _lib.MliError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load_library() must raise when the HIP library is absent")
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from min_llm_inference_amd import ops, MliError
+    t = torch.zeros(4, 8)
+    try:
+        ops._p(t)
+    except MliError:
+        pass
+    else:
+        raise AssertionError("host tensors must not cross the C ABI")

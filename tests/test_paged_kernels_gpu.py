@@ -1,0 +1,184 @@
+"""GPU parity, paged KV layout: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Mirrors the reference's tests/paged_attention_kernels_test.cpp:9-233, paged_attention_cublas_test.cpp:10-184
+and warp_tiling_test.cpp:12-44.  The reference has no CPU paged function: its tier-2 tests compare the
+paged GPU kernels with the contiguous ones through the page layout (assert_page_table_close).  Here the
+contiguous CPU oracle produces the expectation and the page layout rule (include/utils.h:32-60, restated
+in oracle_cpu.c) maps it into a host mirror of the shuffled page pool, so the WHOLE pool is compared --
+bytes the op must not touch have to be bit-identical.
+"""
+import numpy as np
+import pytest
+
+from gpu_util import host, to_dev
+from helpers import (PAGE, assert_close, assert_equal, gather_rows_from_pool, paged_case, scatter_rows_to_pool)
+
+pytestmark = pytest.mark.gpu
+
+# (seed, B, S, D): the reference draws B in [128,256], S in 16*[4,16], D in 4*[128,256]
+SHAPES = [
+    (21, 128, 64, 512),
+    (22, 200, 256, 516),
+    (23, 256, 208, 1024),
+    (24, 37, 128, 64),
+    (25, 16, 1024, 256),   # config 3 shape, reduced batch
+    (26, 3, 4096, 512),    # config 4 shape, reduced batch (multi-chunk split-sequence path)
+    (27, 5, 128, 2048),    # the README workload's emb_dim
+]
+
+
+def _prepare(oracle, dev, seed, B, S, D, **kw):
+    c = paged_case(seed, B, S, D, **kw)
+    oracle.clone_to_pages(c["pool"], c["table"], c["inp_embedding"], c["kt_cache"], c["v_cache"], c["lengths"])
+    return c, to_dev(c, dev)
+
+
+def test_clone_matches_oracle_bit_exact(oracle, mli, dev):
+    """launch_clone_inp_embedding_k_v_cache: pure data movement, so the pools must be identical."""
+    from min_llm_inference_amd import ops
+    lengths = np.random.default_rng(20).integers(0, 128, size=61).astype(np.int32)
+    lengths[:4] = [0, 1, 127, 16]
+    c = paged_case(20, 61, 128, 132, lengths=lengths)
+    d = to_dev(c, dev)
+    ops.launch_clone_inp_embedding_k_v_cache(d["page_table"], d["inp_embedding"], d["kt_cache"], d["v_cache"],
+                                             d["lengths"])
+    oracle.clone_to_pages(c["pool"], c["table"], c["inp_embedding"], c["kt_cache"], c["v_cache"], c["lengths"])
+    assert_equal(host(d["pool"]), c["pool"], what="pool after clone")
+
+
+@pytest.mark.parametrize("variant", ["plain", "warp_tiling"])
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_fill_new_k_v_cache(oracle, mli, dev, seed, B, S, D, variant):
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D)
+    fn = (ops.launch_fill_new_k_v_cache_paged_attention if variant == "plain"
+          else ops.launch_fill_new_k_v_cache_paged_attention_warp_tiling)
+    fn(d["page_table"], d["new_batch_idx"], d["lengths"], d["wk"], d["wv"], c["n_new"], S)
+    oracle.fill_new_kt_v_cache(c["inp_embedding"], c["new_batch_idx"], c["lengths"], c["wk"], c["wv"], c["kt_cache"],
+                               c["v_cache"], c["n_new"])
+    rows = [(int(b), s) for b in c["new_batch_idx"][:c["n_new"]] for s in range(int(c["lengths"][b]))]
+    expect = c["pool"].copy()
+    if rows:
+        bb = np.array([r[0] for r in rows]); ss = np.array([r[1] for r in rows])
+        scatter_rows_to_pool(expect, c["table"], rows, 1, c["kt_cache"][bb, :, ss])
+        scatter_rows_to_pool(expect, c["table"], rows, 2, c["v_cache"][bb, ss, :])
+    assert_close(host(d["pool"]), expect, what="page pool after fill")
+
+
+@pytest.mark.parametrize("variant", ["plain", "cublas"])
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_get_latest_k_q_v(oracle, mli, dev, seed, B, S, D, variant):
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=6)
+    ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"],
+                                                d["q_output"], S)
+    oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
+                             c["q_output"])
+    rows = [(b, int(c["lengths"][b]) - 1) for b in range(B) if c["lengths"][b] > 0]
+    bb = np.array([r[0] for r in rows]); ss = np.array([r[1] for r in rows])
+    expect = c["pool"].copy()
+    scatter_rows_to_pool(expect, c["table"], rows, 1, c["kt_cache"][bb, :, ss])
+    scatter_rows_to_pool(expect, c["table"], rows, 2, c["v_cache"][bb, ss, :])
+    assert_close(host(d["pool"]), expect, what="page pool after latest")
+    assert_close(host(d["q_output"]), c["q_output"], what="q_output")  # rows with length 0 untouched
+
+
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_qkt(oracle, mli, dev, seed, B, S, D):
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=9)
+    ops.launch_qkt_paged_attention(d["q_output"], d["page_table"], d["lengths"], d["qkt_output"])
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    assert_close(host(d["qkt_output"]), c["qkt_output"], what="qkt_output")
+
+
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_softmax_v(oracle, mli, dev, seed, B, S, D):
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=4)
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    d = to_dev(c, dev)
+    ops.launch_softmax_v_paged_attention(d["qkt_output"], d["page_table"], d["attention_result"], d["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+
+
+@pytest.mark.parametrize("variant", ["paged_attention", "paged_attention_with_cublas"])
+@pytest.mark.parametrize("conditioned", [False, True])
+@pytest.mark.parametrize("zero_every", [None, 5])
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_paged_attention_composition(oracle, mli, dev, seed, B, S, D, zero_every, conditioned, variant):
+    """reference InferenceOptimizedSelfAttentionTest / ...ZeroLengthTest (paged_attention_kernels_test.cpp:114-233)."""
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=zero_every, conditioned=conditioned)
+    getattr(ops, variant)(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["q_output"],
+                          d["qkt_output"], d["attention_result"], c["n_new"], S)
+    oracle.self_attention_inference_host(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"],
+                                         c["new_batch_idx"], c["kt_cache"], c["v_cache"], c["q_output"],
+                                         c["qkt_output"], c["attention_result"], c["n_new"])
+    pool = host(d["pool"])
+    lengths = c["lengths"]
+    k_got = oracle.gather_from_pages(pool, c["table"], lengths, S, D, 1)
+    v_got = oracle.gather_from_pages(pool, c["table"], lengths, S, D, 2)
+    for b in range(B):  # the comparison domain of assert_page_table_close: s < length
+        L = int(lengths[b])
+        if L:
+            # K/V rows written by this call (new rows: all of s < L; every non-empty row: s = L-1)
+            rows = range(L) if b in set(c["new_batch_idx"][:c["n_new"]].tolist()) else [L - 1]
+            rows = list(rows)
+            assert_close(k_got[b, rows, :], c["kt_cache"][b][:, rows].T, what=f"K row {b}")
+            assert_close(v_got[b, rows, :], c["v_cache"][b, rows, :], what=f"V row {b}")
+    assert_close(host(d["q_output"]), c["q_output"], what="q_output")
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+    if conditioned:
+        assert_close(host(d["qkt_output"]), c["qkt_output"], what="qkt_output (probabilities)")
+
+
+def test_page_table_indexing_bit_exact(oracle, mli, dev):
+    """Integer-valued data make every fp32 sum exact in any order, so any mismatch is an INDEXING error:
+    wrong page, wrong slot, wrong segment or wrong column.  Edge lengths 0, 1, 15, 16, 17, S-1 included."""
+    from min_llm_inference_amd import ops
+    B, S, D = 24, 256, 132
+    rng = np.random.default_rng(77)
+    lengths = rng.integers(0, S, size=B).astype(np.int32)
+    lengths[:6] = [0, 1, 15, 16, 17, S - 1]
+    c = paged_case(78, B, S, D, lengths=lengths)
+    for k in ("inp_embedding", "kt_cache", "v_cache", "q_output", "wk", "wq", "wv"):
+        c[k] = rng.integers(0, 4, size=c[k].shape).astype(np.float32)
+    c["qkt_output"] = (rng.integers(0, 8, size=c["qkt_output"].shape) / 8.0).astype(np.float32)  # dyadic "probabilities"
+    c["pool"] = rng.integers(0, 4, size=c["pool"].shape).astype(np.float32)
+    oracle.clone_to_pages(c["pool"], c["table"], c["inp_embedding"], c["kt_cache"], c["v_cache"], c["lengths"])
+    d = to_dev(c, dev)
+
+    # qkt: K gathered from the right (page, slot, segment)
+    ops.launch_qkt_paged_attention(d["q_output"], d["page_table"], d["lengths"], d["qkt_output"])
+    exp_q = c["qkt_output"].copy()
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], exp_q)
+    assert_equal(host(d["qkt_output"]), exp_q, what="qkt (bit exact)")
+
+    # softmax_v: V gathered from the right place (dyadic weights keep every product and sum exact)
+    import torch
+    probs = (rng.integers(0, 8, size=(B, S)) / 8.0).astype(np.float32)
+    ops.launch_softmax_v_paged_attention(torch.from_numpy(probs).to(dev), d["page_table"], d["attention_result"],
+                                         d["lengths"])
+    exp_a = c["attention_result"].copy()
+    oracle.softmax_v_host(probs, c["v_cache"], exp_a, c["lengths"])
+    assert_equal(host(d["attention_result"]), exp_a, what="softmax_v (bit exact)")
+
+    # fill + latest: x read from segment 0, K/V written to segments 1/2 of the right slot; nothing else touched
+    ops.launch_fill_new_k_v_cache_paged_attention(d["page_table"], d["new_batch_idx"], d["lengths"], d["wk"], d["wv"],
+                                                  c["n_new"], S)
+    ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"],
+                                                d["q_output"], S)
+    oracle.fill_new_kt_v_cache(c["inp_embedding"], c["new_batch_idx"], c["lengths"], c["wk"], c["wv"], c["kt_cache"],
+                               c["v_cache"], c["n_new"])
+    oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
+                             c["q_output"])
+    rows = sorted({(int(b), s) for b in c["new_batch_idx"][:c["n_new"]] for s in range(int(c["lengths"][b]))} |
+                  {(b, int(c["lengths"][b]) - 1) for b in range(B) if c["lengths"][b] > 0})
+    bb = np.array([r[0] for r in rows]); ss = np.array([r[1] for r in rows])
+    expect = c["pool"].copy()
+    scatter_rows_to_pool(expect, c["table"], rows, 1, c["kt_cache"][bb, :, ss])
+    scatter_rows_to_pool(expect, c["table"], rows, 2, c["v_cache"][bb, ss, :])
+    assert_equal(host(d["pool"]), expect, what="page pool (bit exact)")
+    assert_equal(host(d["q_output"]), c["q_output"], what="q_output (bit exact)")
