@@ -170,6 +170,13 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
                                       const float* kt_cache, const float* v_cache, const int* lengths,
                                       int n_batch, int n_sequence, int emb_dim, void* stream);
 
+/* Tuning / diagnostic knobs (process-wide; results are identical for every setting):
+ *   "chunk_tokens"     0 = heuristic, else a power of two in [64, 1024]: tokens per workgroup of the
+ *                      split-sequence kernels
+ *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
+ *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch */
+int mli_tune(const char* key, int value);
+
 /* float4 device copy used by bench.py to measure the achievable HBM copy rate on the box. */
 int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream);
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mli_decoder": [_P] * 7 + [_I] * 4 + [_P],
     "mli_paged_decoder_multi_rounds": [_P] * 7 + [_I] * 6 + [_P],
     "mli_clone_inp_embedding_k_v_cache": [_P] * 5 + [_I] * 3 + [_P],
+    "mli_tune": [ctypes.c_char_p, _I],
     "mli_stream_copy": [_P, _P, _Z, _P],
 }
 _RESTYPES = {"mli_attention_workspace_bytes": _Z}

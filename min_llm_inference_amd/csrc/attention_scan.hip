@@ -9,6 +9,8 @@
 // transposing wave butterfly (17 exchanges per 16 tokens); the sequence is cut into fixed-size
 // chunks (grid.x) so that ragged row lengths still give evenly sized work units, with a tiny
 // fixed-order combine pass for softmax.V (bitwise reproducible, no float atomics).
+#include <string>
+
 #include "device_common.hpp"
 
 namespace mli {
@@ -18,8 +20,14 @@ constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kMaxChunkTokens = 1024;
 constexpr int kMinChunkTokens = 64;
 
+// Tuning knobs (mli_tune): 0 = use the built-in heuristic / default.
+static int g_chunk_tokens = 0;
+static int g_nt_loads = 1;
+static int g_qkt_token_batch = 8;
+
 // Sequence chunk (tokens per workgroup) for the split-sequence kernels: the largest
-// power of two in [64, 1024] that still yields >= 8192 work units.
+// power of two in [64, 1024] that still yields >= 16384 work units (measured on MI355X: 256 at
+// B=1024, S=4096; with rows as the fast grid dimension the choice is worth only a few percent).
 // MLI_CHUNK_TOKENS (power of two in [64, 1024]) overrides the heuristic for tuning runs.
 static int pick_chunk_tokens(int n_batch, int n_sequence) {
     static const int forced = [] {
@@ -28,21 +36,26 @@ static int pick_chunk_tokens(int n_batch, int n_sequence) {
         return (v >= kMinChunkTokens && v <= kMaxChunkTokens && (v & (v - 1)) == 0) ? v : 0;
     }();
     if (forced) return forced;
+    if (g_chunk_tokens) return g_chunk_tokens;
     int ct = kMaxChunkTokens;
-    while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < 8192) ct >>= 1;
+    while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < 16384) ct >>= 1;
     return ct;
 }
 
 // ------------------------------------------------------------------------------------------
-// qkt, paged layout.  grid = (ceil(S / ct), B), block = 256.  Each wave takes whole pages.
+// qkt, paged layout.  grid = (B, ceil(S / ct)), block = 256.  Each wave takes whole pages.
 // ------------------------------------------------------------------------------------------
+template <int TB, bool NT>
 __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
     const float* __restrict__ q, const float* const* __restrict__ page_table,
     const int* __restrict__ lengths, float* __restrict__ qkt, int S, int D, int ct) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int b = blockIdx.y;
+    // grid = (B, chunks): the row index is the fast dimension, so consecutive workgroups (which the
+    // dispatcher deals round-robin to the 8 XCDs) are different rows of the SAME chunk -- every XCD
+    // gets an equal share of each chunk, and the empty high chunks are dispatched last.
+    const int b = blockIdx.x;
     const int L = lengths[b];
-    const int s0 = blockIdx.x * ct;
+    const int s0 = blockIdx.y * ct;
     if (s0 >= L) return;  // same early exit as the reference (paged_attention.cu:233-235)
 
     const int W = S / kPage;
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
     const int nj = (D4 + kWave - 1) / kWave;
 
     for (int pi = wave; pi < npages; pi += kScanWaves) {
-        const float* page = ptr_sh[pi];
+        const float* page = wave_uniform(ptr_sh[pi]);
         const float* krow = page + D;  // segment 1 of token slot 0
         float acc[16];
 #pragma unroll
@@ -74,12 +87,18 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
             const int i4 = lane + j * kWave;
             if (i4 < D4) {
                 const float4 qv = q_sh[i4];
-                float4 kv[16];
+                const unsigned voff = (unsigned)i4 * 16u;  // per-lane BYTE offset: one 32-bit VGPR
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    kv[t] = *reinterpret_cast<const float4*>(krow + (int64_t)t * 3 * D + (int64_t)i4 * 4);
+                for (int h = 0; h < 16 / TB; ++h) {
+                    float4 kv[TB];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc[t] = dot4(qv, kv[t], acc[t]);
+                    for (int t = 0; t < TB; ++t) {
+                        const float* trow = krow + (int64_t)(h * TB + t) * 3 * D;  // wave-uniform: stays in SGPRs
+                        kv[t] = ldg4<NT>(byte_offset(trow, voff));
+                    }
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) acc[h * TB + t] = dot4(qv, kv[t], acc[h * TB + t]);
+                }
             }
         }
         const float tot = wave_reduce16(acc, lane);
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
 // ------------------------------------------------------------------------------------------
 // qkt, contiguous layout kt_cache[B, D, S].  Lanes run along s (float4 = 4 tokens per lane);
 // the 4 waves of a workgroup split d and are summed in fixed order through LDS.
-// grid = (ceil(S / 256), B).
+// grid = (B, ceil(S / 256)).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
     const float* __restrict__ q, const float* __restrict__ kt, const int* __restrict__ lengths,
@@ -99,9 +118,9 @@ __global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4 (*red)[kWave] = reinterpret_cast<float4 (*)[kWave]>(smem_raw);                // [waves][64] float4
     float* q_sh = reinterpret_cast<float*>(smem_raw + sizeof(float4) * kScanWaves * kWave);  // D floats
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
     const int L = lengths[b];
-    const int s0 = blockIdx.x * 256;
+    const int s0 = blockIdx.y * 256;
     if (s0 >= L) return;  // reference …optimized.cu:160-162
     for (int i = threadIdx.x; i < D; i += kScanThreads) q_sh[i] = q[(int64_t)b * D + i];
     __syncthreads();
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(kScanThreads) void softmax_lengths_kernel(
 
 // ------------------------------------------------------------------------------------------
 // softmax.V partial sums.  VEC floats per lane per load (4 when rows are 16-byte aligned),
-// NJ loads per row slice; grid = (nchunks, B, d_slices).  A slice covers 64*VEC*NJ columns.
+// NJ loads per row slice; grid = (B, nchunks, d_slices).  A slice covers 64*VEC*NJ columns.
 // direct != 0: single chunk per row, result goes straight to attention_result.
 // ------------------------------------------------------------------------------------------
 template <int VEC> struct VecT;
@@ -214,7 +233,13 @@ template <int VEC> __device__ __forceinline__ void vadd(typename VecT<VEC>::type
 template <> __device__ __forceinline__ void vadd<4>(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 template <> __device__ __forceinline__ void vadd<1>(float& a, const float& b) { a += b; }
 
-template <int VEC, int NJ, bool PAGED>
+template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type vload(const typename VecT<VEC>::type* p, bool nt);
+template <> __device__ __forceinline__ float4 vload<4>(const float4* p, bool nt) {
+    return nt ? ldg4<true>(reinterpret_cast<const float*>(p)) : ldg4<false>(reinterpret_cast<const float*>(p));
+}
+template <> __device__ __forceinline__ float vload<1>(const float* p, bool nt) { return nt ? ldg1<true>(p) : ldg1<false>(p); }
+
+template <int VEC, int NJ, bool PAGED, bool NT>
 __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
     const float* __restrict__ probs, const void* __restrict__ src, const int* __restrict__ lengths,
     float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct) {
@@ -225,8 +250,8 @@ __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
     const float** ptr_sh = reinterpret_cast<const float**>(smem_raw + (size_t)ct * 4);  // ct/16 pointers
     V* red = reinterpret_cast<V*>(smem_raw + (size_t)ct * 4 + (size_t)(ct / kPage) * 8);  // [waves][kSliceV]
 
-    const int b = blockIdx.y;
-    const int c = blockIdx.x;
+    const int b = blockIdx.x;  // rows are the fast grid dimension (XCD balance, see qkt_paged_kernel)
+    const int c = blockIdx.y;
     const int L = min(lengths[b], S);
     const int s0 = c * ct;
     const int Dv = D / VEC;
@@ -262,32 +287,30 @@ __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
     for (int j = 0; j < NJ; ++j) live[j] = (v0 + lane + j * kWave) < Dv;
 
     const int ngroups = (ntok + kPage - 1) / kPage;  // 16-token groups (pages when PAGED)
+    constexpr int TB = 4;                            // rows in flight per load batch (x NJ loads each)
+    const unsigned lane_bytes = (unsigned)(v0 + lane) * (unsigned)sizeof(V);
+    const int64_t stride_f = PAGED ? 3 * (int64_t)D : (int64_t)D;  // floats between consecutive tokens
     for (int g = wave; g < ngroups; g += kScanWaves) {
-        const V* row0;
-        int64_t stride;  // in V units between consecutive tokens
-        if (PAGED) {
-            row0 = reinterpret_cast<const V*>(ptr_sh[g] + 2 * (int64_t)D);
-            stride = 3 * (int64_t)Dv;
-        } else {
-            row0 = reinterpret_cast<const V*>(reinterpret_cast<const float*>(src) +
-                                              ((int64_t)b * S + s0 + g * kPage) * D);
-            stride = Dv;
-        }
-        row0 += v0 + lane;
+        // wave-uniform base of the group's first V row (SGPRs); lanes add one 32-bit byte offset
+        const float* base = PAGED ? wave_uniform(ptr_sh[g]) + 2 * (int64_t)D
+                                  : reinterpret_cast<const float*>(src) + ((int64_t)b * S + s0 + g * kPage) * D;
         const int nt = min(kPage, ntok - g * kPage);
         const float* pg = p_sh + g * kPage;
         if (nt == kPage) {
+#pragma unroll 1
+            for (int h = 0; h < kPage / TB; ++h) {
+                V vb[TB][NJ];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                V vb[8][NJ];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < TB; ++t) {
+                    const float* trow = base + (int64_t)(h * TB + t) * stride_f;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        if (live[j]) vb[t][j] = row0[(int64_t)(h * 8 + t) * stride + j * kWave];
+                        if (live[j])
+                            vb[t][j] = vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT);
+                }
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float p = pg[h * 8 + t];
+                for (int t = 0; t < TB; ++t) {
+                    const float p = pg[h * TB + t];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         if (live[j]) vfma<VEC>(p, vb[t][j], acc[j]);
@@ -296,9 +319,11 @@ __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
         } else {
             for (int t = 0; t < nt; ++t) {
                 const float p = pg[t];
+                const float* trow = base + (int64_t)t * stride_f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    if (live[j]) vfma<VEC>(p, row0[(int64_t)t * stride + j * kWave], acc[j]);
+                    if (live[j])
+                        vfma<VEC>(p, vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT), acc[j]);
             }
         }
     }
@@ -346,7 +371,7 @@ template <int VEC, bool PAGED>
 static int launch_softmax_v_impl(const float* probs, const void* src, const int* lengths, float* out,
                                  int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
     const int Dv = D / VEC;
-    const int nj = min(4, ceil_div_i(Dv, kWave));
+    const int nj = min(2, ceil_div_i(Dv, kWave));  // <= 64 VGPRs -> 8 waves/SIMD; wider rows become d-slices (grid.z)
     const int slice_v = kWave * nj;
     const int nslices = ceil_div_i(Dv, slice_v);
     int ct = pick_chunk_tokens(B, S);
@@ -359,16 +384,18 @@ static int launch_softmax_v_impl(const float* probs, const void* src, const int*
         dst = reinterpret_cast<float*>(workspace);
     }
     const size_t smem = (size_t)ct * 4 + (size_t)(ct / kPage) * 8 + (size_t)kScanWaves * slice_v * VEC * 4;
-    dim3 grid(nchunk, B, nslices);
-#define MLI_SV_LAUNCH(NJ)                                                                         \
-    hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED>), grid, dim3(kScanThreads), smem, st, \
-                       probs, src, lengths, dst, S, D, ct, nchunk, direct)
-    switch (nj) {
-        case 1: MLI_SV_LAUNCH(1); break;
-        case 2: MLI_SV_LAUNCH(2); break;
-        case 3: MLI_SV_LAUNCH(3); break;
-        default: MLI_SV_LAUNCH(4); break;
-    }
+    dim3 grid(B, nchunk, nslices);
+#define MLI_SV_LAUNCH(NJ)                                                                                  \
+    do {                                                                                                   \
+        if (g_nt_loads)                                                                                    \
+            hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED, true>), grid, dim3(kScanThreads), smem, st, \
+                               probs, src, lengths, dst, S, D, ct, nchunk, direct);                        \
+        else                                                                                               \
+            hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED, false>), grid, dim3(kScanThreads), smem, st, \
+                               probs, src, lengths, dst, S, D, ct, nchunk, direct);                        \
+    } while (0)
+    if (nj == 1) MLI_SV_LAUNCH(1);
+    else MLI_SV_LAUNCH(2);
 #undef MLI_SV_LAUNCH
     int rc = launch_status();
     if (rc || direct) return rc;
@@ -382,15 +409,20 @@ int launch_qkt_paged(const float* q, const float* const* page_table, const int* 
     if (S % kPage != 0 || D % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
     const int ct = pick_chunk_tokens(B, S);
     const size_t smem = (size_t)D * 4 + (size_t)(ct / kPage) * 8;
-    hipLaunchKernelGGL(qkt_paged_kernel, dim3(ceil_div_i(S, ct), B), dim3(kScanThreads), smem, st,
-                       q, page_table, lengths, qkt, S, D, ct);
+    dim3 grid(B, ceil_div_i(S, ct));
+#define MLI_QKT_LAUNCH(TB, NT) \
+    hipLaunchKernelGGL((qkt_paged_kernel<TB, NT>), grid, dim3(kScanThreads), smem, st, q, page_table, lengths, qkt, S, D, ct)
+    if (g_qkt_token_batch == 16) { if (g_nt_loads) MLI_QKT_LAUNCH(16, true); else MLI_QKT_LAUNCH(16, false); }
+    else if (g_qkt_token_batch == 4) { if (g_nt_loads) MLI_QKT_LAUNCH(4, true); else MLI_QKT_LAUNCH(4, false); }
+    else { if (g_nt_loads) MLI_QKT_LAUNCH(8, true); else MLI_QKT_LAUNCH(8, false); }
+#undef MLI_QKT_LAUNCH
     return launch_status();
 }
 
 int launch_qkt_naive(const float* q, const float* kt, const int* lengths, float* qkt, int B, int S, int D,
                      hipStream_t st) {
     if (S % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(qkt_naive_kernel, dim3(ceil_div_i(S, 256), B), dim3(kScanThreads),
+    hipLaunchKernelGGL(qkt_naive_kernel, dim3(B, ceil_div_i(S, 256)), dim3(kScanThreads),
                        sizeof(float4) * kScanWaves * kWave + (size_t)D * 4, st, q, kt, lengths, qkt, S, D);
     return launch_status();
 }
@@ -456,6 +488,22 @@ int mli_softmax_v_paged(const float* softmax_result, const float* const* page_ta
                         size_t workspace_bytes, void* stream) {
     return mli::launch_softmax_v_paged(softmax_result, page_table, lengths, attention_result, n_batch, n_sequence,
                                        emb_dim, workspace, workspace_bytes, mli::as_stream(stream));
+}
+
+int mli_tune(const char* key, int value) {
+    const std::string k(key ? key : "");
+    if (k == "chunk_tokens") {
+        if (value != 0 && (value < mli::kMinChunkTokens || value > mli::kMaxChunkTokens || (value & (value - 1)))) return MLI_ERR_BAD_ARG;
+        mli::g_chunk_tokens = value;
+    } else if (k == "nt_loads") {
+        mli::g_nt_loads = value != 0;
+    } else if (k == "qkt_token_batch") {
+        if (value != 4 && value != 8 && value != 16) return MLI_ERR_BAD_ARG;
+        mli::g_qkt_token_batch = value;
+    } else {
+        return MLI_ERR_BAD_ARG;
+    }
+    return 0;
 }
 
 int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream) {

@@ -19,6 +19,41 @@ __device__ __forceinline__ int64_t page_row_offset(int i_sequence, int emb_dim, 
     return (int64_t)(i_sequence % kPage) * emb_dim * 3 + (int64_t)seg * emb_dim;
 }
 
+// Loads through pointers that came out of LDS (page pointers) would otherwise be FLAT loads: the
+// compiler cannot prove the address space.  Casting to address space 1 yields global_load_dwordx4;
+// NT adds the non-temporal hint for streams that are read exactly once (K/V pages).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gv4_ptr;
+
+template <bool NT>
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    f32x4_t v;
+    if (NT) v = __builtin_nontemporal_load((gv4_ptr)(p));
+    else v = *(gv4_ptr)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// A pointer every lane of the wave holds the same value of (a page pointer read from LDS): move it
+// to SGPRs so the loads use the scalar-base form and no per-lane 64-bit address math is needed.
+__device__ __forceinline__ const float* wave_uniform(const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<const float*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// uniform base + zero-extended 32-bit per-lane byte offset: the shape the global_load saddr form wants
+__device__ __forceinline__ const float* byte_offset(const float* base, unsigned bytes) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + bytes);
+}
+
+typedef const float __attribute__((address_space(1)))* gf_ptr;
+template <bool NT>
+__device__ __forceinline__ float ldg1(const float* p) {
+    if (NT) return __builtin_nontemporal_load((gf_ptr)(p));
+    return *(gf_ptr)(p);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));

@@ -1,0 +1,93 @@
+// Standalone HBM read micro-benchmark: what can a pure streaming read reach on this box, for the
+// access shapes the decode kernels use?  Build: hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o tools/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// each wave reads `rows_per_wave` rows of `row_f4` float4 (contiguous), rows spaced `stride_f4` apart.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_rows(const float4* __restrict__ src, float* __restrict__ sink,
+                                                  long rows_total, int row_f4, long stride_f4) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.f;
+    const int per_row = (row_f4 + 63) / 64;
+    for (long r0 = wave * UNROLL; r0 < rows_total; r0 += nwaves * UNROLL) {
+        for (int j = 0; j < per_row; ++j) {
+            float4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                long r = r0 + u;
+                int i = lane + j * 64;
+                v[u] = (r < rows_total && i < row_f4) ? src[r * stride_f4 + i] : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+template <typename F>
+float time_ms(F f, int reps) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main() {
+    const long n4 = 1L << 28;  // 4 GiB source
+    float4 *src, *dst; float* sink;
+    CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(src, 1, n4 * 16));
+    for (int grid : {1024, 2048, 4096, 8192, 16384}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(grid), dim3(256), 0, 0, src, dst, n4); }, 5);
+        printf("copy unroll4 grid %5d: %.1f GB/s (r+w)\n", grid, 2.0 * n4 * 16 / ms / 1e6);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<8>, dim3(4096), dim3(256), 0, 0, src, dst, n4); }, 5);
+        printf("copy unroll8 grid  4096: %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
+        ms = time_ms([&] { CK(hipMemcpyAsync(dst, src, n4 * 16, hipMemcpyDeviceToDevice, 0)); }, 5);
+        printf("hipMemcpy D2D         : %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
+    }
+    // contiguous rows of 2 KiB (128 float4): pure streaming read
+    struct Shape { const char* name; int row_f4; long stride_f4; };
+    Shape shapes[] = {{"contig 2KiB rows", 128, 128}, {"2KiB @ 6KiB stride (K of fp32 pages D=512)", 128, 384},
+                      {"4KiB @ 6KiB stride (K|V of fp32 pages)", 256, 384}, {"1KiB @ 3KiB stride (D=256)", 64, 192}};
+    for (auto& sh : shapes) {
+        long rows = (n4 - sh.row_f4) / sh.stride_f4;
+        for (int grid : {2048, 4096, 8192}) {
+            float ms4 = time_ms([&] { hipLaunchKernelGGL(read_rows<4>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float ms8 = time_ms([&] { hipLaunchKernelGGL(read_rows<8>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float ms16 = time_ms([&] { hipLaunchKernelGGL(read_rows<16>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            double bytes = (double)rows * sh.row_f4 * 16;
+            printf("read %-44s grid %5d: u4 %.0f  u8 %.0f  u16 %.0f GB/s\n", sh.name, grid, bytes / ms4 / 1e6, bytes / ms8 / 1e6, bytes / ms16 / 1e6);
+        }
+    }
+    return 0;
+}
