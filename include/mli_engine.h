@@ -1,0 +1,74 @@
+/*
+ * mli_engine.h -- C ABI over the host engine loops (continuous batching + paged KV allocator) of
+ * libmli_hip.so.  It binds what the reference exposes as C++ only:
+ *   start_inference_engine / start_paged_attention_inference_engine /
+ *   start_paged_attention_cublas_inference_engine       (reference include/inferencer.h:18-32)
+ * together with the objects their callers build first (ItemStorage, ProcessingStorage,
+ * MemoryBlockManager, PagedAttentionsManager, *InferenceModel; reference tests/paged_for_profile.cpp:10-62).
+ * One engine drives one GPU.  bench.py and the tests use it through ctypes; a C++ host links the classes
+ * directly (min_llm_inference_amd/host/include).
+ */
+#ifndef MLI_ENGINE_H
+#define MLI_ENGINE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mli_engine mli_engine;
+
+enum { MLI_ENGINE_CONTIGUOUS = 0, MLI_ENGINE_PAGED = 1, MLI_ENGINE_PAGED_GEMM = 2 };
+
+typedef struct {
+    int kind;             /* MLI_ENGINE_* */
+    int n_batch;          /* slots in the continuous batch */
+    int n_sequence;       /* max tokens per item (multiple of 16 for the paged kinds) */
+    int emb_dim;          /* multiple of 4 */
+    int n_vocab;
+    int n_blocks;         /* paged: pages in the pool (each 16 * 3 * emb_dim floats) */
+    int n_forward_rounds; /* paged: decode rounds per iteration, 1..16 */
+    int device;           /* GPU ordinal this engine runs on */
+    int reference_length_reset_quirk; /* 1 = reproduce src/paged_item_storage.cpp:110-118 (measurement only) */
+} mli_engine_config;
+
+typedef struct {
+    long long total_tokens; /* tokens appended by process_decoder_result (ThroughputCounter) */
+    double seconds;         /* wall time since the first insert, host work and copies included */
+    long long iterations;   /* engine iterations executed */
+    int finished;           /* items finished */
+    int waiting;            /* items still queued */
+    int in_flight;          /* items occupying a slot */
+} mli_engine_stats;
+
+/* Weights are HOST pointers (row-major fp32): emb_table [n_vocab, emb_dim], pos_table [n_sequence, emb_dim],
+ * wk/wq/wv [emb_dim, emb_dim]; they are copied to the device.  Returns 0 or a negative error
+ * (mli_engine_last_error() has the message). */
+int mli_engine_create(const mli_engine_config* config, const float* emb_table, const float* pos_table,
+                      const float* wk, const float* wq, const float* wv, mli_engine** out);
+void mli_engine_destroy(mli_engine* engine);
+
+/* Queue one item (ItemStorage::add_new_item). */
+int mli_engine_add_item(mli_engine* engine, int id, const int* tokens, int n_tokens);
+
+/* Run to completion (the reference's start_*_engine). */
+int mli_engine_run(mli_engine* engine, mli_engine_stats* stats);
+
+/* One iteration: forward -> process_decoder_result -> page bookkeeping -> insert_new_items.  The first call
+ * also performs the initial insert.  *done is set to 1 once every item has finished. */
+int mli_engine_step(mli_engine* engine, int* done);
+
+int mli_engine_get_stats(mli_engine* engine, mli_engine_stats* stats);
+
+/* Device pointer to the int32 decoder output of the last iteration, [n_batch, n_forward_rounds]
+ * (what a multi-GPU host all-gathers), and its element count. */
+int mli_engine_decoder_result(mli_engine* engine, void** device_ptr, int* count);
+
+/* Finished item `index` (0 <= index < stats.finished), in completion order: id and tokens (prompt + generated). */
+int mli_engine_get_finished(mli_engine* engine, int index, int* id, int* tokens, int capacity, int* n_tokens);
+
+const char* mli_engine_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLI_ENGINE_H */

@@ -19,6 +19,10 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64 / libhsa-runtime64.  Import it FIRST so that libmli_hip.so's
+    # libamdhip64.so.7 dependency resolves to the copy already in the process; loading /opt/rocm's runtime
+    # beside torch's gives two HSA runtimes in one process, and the second one to initialise sees no GPU.
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise MliError(
@@ -57,11 +61,37 @@ SIGNATURES = {
     "mli_tune": [ctypes.c_char_p, _I],
     "mli_stream_copy": [_P, _P, _Z, _P],
 }
-_RESTYPES = {"mli_attention_workspace_bytes": _Z}
+class EngineConfig(ctypes.Structure):
+    """mli_engine_config (include/mli_engine.h)."""
+    _fields_ = [("kind", _I), ("n_batch", _I), ("n_sequence", _I), ("emb_dim", _I), ("n_vocab", _I),
+                ("n_blocks", _I), ("n_forward_rounds", _I), ("device", _I), ("reference_length_reset_quirk", _I)]
+
+
+class EngineStats(ctypes.Structure):
+    """mli_engine_stats (include/mli_engine.h)."""
+    _fields_ = [("total_tokens", ctypes.c_longlong), ("seconds", ctypes.c_double), ("iterations", ctypes.c_longlong),
+                ("finished", _I), ("waiting", _I), ("in_flight", _I)]
+
+
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_IP = ctypes.POINTER(_I)
+ENGINE_SIGNATURES = {
+    "mli_engine_create": [ctypes.POINTER(EngineConfig), _P, _P, _P, _P, _P, _PP],
+    "mli_engine_destroy": [_P],
+    "mli_engine_add_item": [_P, _I, _P, _I],
+    "mli_engine_run": [_P, ctypes.POINTER(EngineStats)],
+    "mli_engine_step": [_P, _IP],
+    "mli_engine_get_stats": [_P, ctypes.POINTER(EngineStats)],
+    "mli_engine_decoder_result": [_P, _PP, _IP],
+    "mli_engine_get_finished": [_P, _I, _IP, _P, _I, _IP],
+    "mli_engine_last_error": [],
+}
+_RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
+             "mli_engine_destroy": None}
 
 
 def _declare(lib):
-    for name, argtypes in SIGNATURES.items():
+    for name, argtypes in list(SIGNATURES.items()) + list(ENGINE_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _I)

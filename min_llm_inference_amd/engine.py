@@ -1,0 +1,82 @@
+"""ctypes front end of the engine C ABI (include/mli_engine.h): continuous batching on one GPU.
+
+Mirrors how the reference's drivers use the engine (tests/paged_for_profile.cpp:10-62): build the item queue
+and the model, then run start_*_engine to completion.  Nothing is computed in Python.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import EngineConfig, EngineStats, MliError, load_library
+
+CONTIGUOUS, PAGED, PAGED_GEMM = 0, 1, 2
+
+
+def _fp(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    def __init__(self, kind, n_batch, n_sequence, emb_dim, n_vocab, emb_table, pos_table, wk, wq, wv, n_blocks=0,
+                 n_forward_rounds=1, device=0, reference_length_reset_quirk=False):
+        self._lib = load_library()
+        self.cfg = EngineConfig(kind, n_batch, n_sequence, emb_dim, n_vocab, n_blocks, n_forward_rounds, device,
+                                int(reference_length_reset_quirk))
+        keep = [_fp(x) for x in (emb_table, pos_table, wk, wq, wv)]
+        assert keep[0][0].shape == (n_vocab, emb_dim) and keep[1][0].shape == (n_sequence, emb_dim)
+        self._h = ctypes.c_void_p()
+        self._check(self._lib.mli_engine_create(ctypes.byref(self.cfg), *[k[1] for k in keep], ctypes.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MliError("Hip Failure: " + (self._lib.mli_engine_last_error() or b"").decode())
+
+    def add_item(self, item_id, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._check(self._lib.mli_engine_add_item(self._h, int(item_id), t.ctypes.data_as(ctypes.c_void_p), len(t)))
+
+    def run(self):
+        st = EngineStats()
+        self._check(self._lib.mli_engine_run(self._h, ctypes.byref(st)))
+        return st
+
+    def step(self):
+        done = ctypes.c_int(0)
+        self._check(self._lib.mli_engine_step(self._h, ctypes.byref(done)))
+        return bool(done.value)
+
+    def stats(self):
+        st = EngineStats()
+        self._check(self._lib.mli_engine_get_stats(self._h, ctypes.byref(st)))
+        return st
+
+    def decoder_result_ptr(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_int()
+        self._check(self._lib.mli_engine_decoder_result(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def finished(self):
+        """[(id, tokens)] in completion order."""
+        out = []
+        cap = self.cfg.n_sequence + 16
+        buf = np.empty(cap, np.int32)
+        for i in range(self.stats().finished):
+            item_id = ctypes.c_int()
+            n = ctypes.c_int()
+            self._check(self._lib.mli_engine_get_finished(self._h, i, ctypes.byref(item_id),
+                                                          buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
+            out.append((item_id.value, buf[:n.value].copy()))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.mli_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

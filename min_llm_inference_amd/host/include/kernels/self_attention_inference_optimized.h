@@ -1,0 +1,32 @@
+// Contiguous-KV decode attention: the five launchers and their composition, with the reference's
+// signatures (include/kernels/self_attention_inference_optimized.h:5-48).  Each is a thin adapter over
+// the C ABI in include/mli_kernels.h.
+//
+// Shapes: inp_embedding [n_batch, n_sequence, input_dim]; lengths [n_batch]; wk/wq/wv [input_dim, output_dim];
+// new_batch_idx [n_batch] (first n_new_items valid); kt_cache [n_batch, output_dim, n_sequence];
+// v_cache [n_batch, n_sequence, output_dim]; q_output [n_batch, output_dim]; qkt_output [n_batch, n_sequence];
+// attention_result [n_batch, output_dim].
+#pragma once
+
+#include "tensor.hpp"
+
+void launch_fill_new_kt_v_cache(const TensorFloat& inp_embedding, const TensorInt& new_batch_idx,
+                                const TensorInt& lengths, const TensorFloat& wk, const TensorFloat& wv,
+                                TensorFloat& kt_cache, TensorFloat& v_cache, int n_new_items);
+
+void launch_get_latest_kt_q_v(const TensorFloat& inp_embedding, const TensorInt& lengths, const TensorFloat& wk,
+                              const TensorFloat& wq, const TensorFloat& wv, TensorFloat& kt_cache,
+                              TensorFloat& v_cache, TensorFloat& q_output);
+
+void launch_qkt(const TensorFloat& q_output, const TensorFloat& kt_cache, const TensorInt& lengths,
+                TensorFloat& qkt_output);
+
+void launch_softmax_in_place_with_lengths(TensorFloat& qkt_output, const TensorInt& lengths);
+
+void launch_softmax_v(const TensorFloat& softmax_result, const TensorFloat& v_cache, TensorFloat& attention_result,
+                      const TensorInt& lengths);
+
+void inference_self_attention(const TensorFloat& inp_embedding, const TensorInt& lengths, const TensorFloat& wk,
+                              const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
+                              TensorFloat& kt_cache, TensorFloat& v_cache, TensorFloat& q_output,
+                              TensorFloat& qkt_output, TensorFloat& attention_result, int n_new_items);

@@ -1,0 +1,26 @@
+// Memory backend behind Tensor<T>.  Product builds link host/src/memory_hip.cpp (hipMalloc /
+// hipHostMalloc / hipMemcpy[Async] on the engine's device); the CPU tests of the host scheduler link a
+// plain-malloc test double instead (tests/cpp/memory_host_double.cpp) -- a link-time substitution, the
+// product library contains no CPU fallback.
+#pragma once
+
+#include <cstddef>
+
+namespace mli {
+namespace mem {
+
+enum class Space { Host, Device };
+enum class Mode { Sync, Async };
+
+struct Block;  // opaque; owns one allocation (+ the readiness event of the async flavour)
+
+Block* acquire(std::size_t bytes, Space space, Mode mode);
+void release(Block* block) noexcept;
+void* pointer(Block* block);                       // async blocks wait for their last copy first
+void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t bytes);  // same offset both sides
+Space space_of(const Block* block);
+Mode mode_of(const Block* block);
+std::size_t size_of(const Block* block);
+
+}  // namespace mem
+}  // namespace mli

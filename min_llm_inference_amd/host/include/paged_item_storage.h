@@ -1,0 +1,68 @@
+// KV page pool, per-row page lists and the host mirror of the device page table
+// (reference include/paged_item_storage.h, src/paged_item_storage.cpp).
+#pragma once
+
+#include <cstddef>
+#include <list>
+#include <utility>
+#include <vector>
+
+#include "item_storage.h"
+#include "tensor.hpp"
+
+// One device allocation of n_blocks * each_block_size floats, handed out in fixed-size blocks.
+// each_block_size = PAGE_BLOCK_SIZE * 3 * emb_dim (input embedding | K | V per token).
+class MemoryBlockManager {
+public:
+    MemoryBlockManager(int n_blocks, size_t each_block_size);
+    int free_blocks_size() const;
+    std::list<float*> pop_free_blocks(int size);  // throws std::runtime_error when fewer are free
+    void return_free_blocks(std::list<float*>&&);
+
+private:
+    TensorFloat block_memory_;
+    std::list<float*> free_blocks_;
+};
+
+using BatchIdMemoryBlocksPair = std::pair<int, std::list<float*>>;
+
+class PagedAttentionsManager {
+public:
+    PagedAttentionsManager(size_t max_batches, size_t n_sequence, size_t emb_dim);
+    std::list<BatchIdMemoryBlocksPair>& get_used_block_list();
+    void maybe_flush_changes();  // host page table -> device, only if something changed
+    void add_batch_block_pair(BatchIdMemoryBlocksPair&&);
+    void set_block_pos(int batch_id, int i_block, float*);
+    TensorFloatPoint& get_page_table_device();
+    int max_blocks_per_row() const { return static_cast<int>(width_); }  // extension: page-table width
+
+private:
+    TensorFloatPoint page_table_host;
+    TensorFloatPoint page_table_device;
+    std::list<BatchIdMemoryBlocksPair> used_blocks_;  // rows in admission order; the tail is preempted first
+    size_t width_;                                    // n_sequence / PAGE_BLOCK_SIZE
+    bool needs_sync_;
+};
+
+// Gives the row one more page (and records it in the host page table).
+void allocate_memory_block(MemoryBlockManager&, PagedAttentionsManager&, BatchIdMemoryBlocksPair&);
+
+// Returns the pages of finished rows, grows rows that are about to cross a page boundary, and preempts
+// rows from the tail of the admission list (back to the head of the queue) when the pool is empty.
+void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager&, MemoryBlockManager&, ProcessingStorage&,
+                                              ItemStorage&, const std::vector<int>& finished_indices,
+                                              int n_forward_rounds);
+
+// Paged engine: admit queued items into free slots while pages last; returns the slots filled.
+std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, TensorInt& lengths_device,
+                                  TensorInt& lengths_host, TensorInt& new_items_indices_device,
+                                  TensorInt& new_items_indices_host, ItemStorage& item_storage,
+                                  ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
+                                  PagedAttentionsManager& paged_attention_manager, int n_forward_rounds);
+
+// The reference's paged insert_new_items uploads lengths_host without ever refreshing it from the device
+// (src/paged_item_storage.cpp:110-118), which resets every in-flight row to its insertion-time length
+// whenever a slot is free.  Default here: in-flight rows keep their true length.  Set to true to
+// reproduce the reference's behaviour (for measurement only).
+void set_reference_length_reset_quirk(bool enabled);
+bool reference_length_reset_quirk();

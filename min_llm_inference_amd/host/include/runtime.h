@@ -1,0 +1,21 @@
+// Per-thread execution context: which GPU this thread drives and which stream kernels go to.
+// The reference is single-GPU and launches everything on the legacy default stream; that stays the
+// default here (compute_stream() == nullptr).  A multi-GPU host creates one engine per GPU, each on its
+// own thread or process, and calls use_device() first.
+#pragma once
+
+namespace mli {
+namespace runtime {
+
+void use_device(int ordinal);          // hipSetDevice for the calling thread
+int current_device();
+void set_compute_stream(void* stream); // hipStream_t as void*; nullptr = legacy default stream
+void* compute_stream();
+void synchronize();                    // hipStreamSynchronize(compute stream) / device sync for the default stream
+
+// roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
+void range_push(const char* name);
+void range_pop();
+
+}  // namespace runtime
+}  // namespace mli

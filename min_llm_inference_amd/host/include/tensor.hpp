@@ -1,0 +1,100 @@
+// Tensor<T>: shape + shared storage.  Same public surface as the reference's include/tensor.hpp
+// (constructor, shape(), device(), data(), copy_from(), get_total_size(), DeviceType, TensorDataType,
+// DEFAULT_ALLOC_METHOD, TensorFloat / TensorInt / TensorFloatPoint; copy construction aliases the
+// storage, HOST tensors are pinned), re-implemented over a small type-erased HIP memory backend
+// (memory.h) instead of one class hierarchy per allocation flavour.
+#pragma once
+
+#include <cstddef>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "memory.h"
+
+enum class DeviceType { HOST, DEVICE };
+
+enum class TensorDataType { SYNC_ALLOCATE = 0, ASYNC_ALLOCATE = 1 };
+
+#ifndef DEFAULT_ALLOC_METHOD
+#define DEFAULT_ALLOC_METHOD 0
+#endif
+
+constexpr TensorDataType DEFAULT_TENSOR_DATA_TYPE = static_cast<TensorDataType>(DEFAULT_ALLOC_METHOD);
+
+// Storage of one tensor.  The reference splits this into SyncTensorData / AsyncTensorData; here the
+// flavour is a property of the backend block.
+template <typename T>
+class TensorData {
+public:
+    TensorData(std::size_t count, DeviceType device, TensorDataType flavour)
+        : count_(count), device_(device),
+          block_(mli::mem::acquire(count * sizeof(T),
+                                   device == DeviceType::HOST ? mli::mem::Space::Host : mli::mem::Space::Device,
+                                   flavour == TensorDataType::SYNC_ALLOCATE ? mli::mem::Mode::Sync
+                                                                            : mli::mem::Mode::Async)) {}
+    TensorData(const TensorData&) = delete;
+    TensorData& operator=(const TensorData&) = delete;
+    ~TensorData() { mli::mem::release(block_); }
+
+    DeviceType device() const { return device_; }
+    T* data() { return static_cast<T*>(mli::mem::pointer(block_)); }
+    const T* data() const { return static_cast<const T*>(mli::mem::pointer(block_)); }
+
+    void copy_from(const TensorData& other) {
+        if (mli::mem::mode_of(other.block_) != mli::mem::mode_of(block_))
+            throw std::runtime_error("Copy from: source uses a different allocation flavour");
+        if (other.count_ != count_) throw std::runtime_error("Copy from: shape or device mismatch");
+        mli::mem::copy(block_, other.block_, 0, count_ * sizeof(T));
+    }
+
+    // Extension (not in the reference): copy elements [first, first + count) only -- lets the scheduler
+    // upload just the batch rows that changed instead of the whole inp[B, S] tensor.
+    void copy_range_from(const TensorData& other, std::size_t first, std::size_t count) {
+        if (mli::mem::mode_of(other.block_) != mli::mem::mode_of(block_))
+            throw std::runtime_error("Copy from: source uses a different allocation flavour");
+        if (other.count_ != count_ || first + count > count_)
+            throw std::runtime_error("Copy from: shape or device mismatch");
+        mli::mem::copy(block_, other.block_, first * sizeof(T), count * sizeof(T));
+    }
+
+private:
+    std::size_t count_;
+    DeviceType device_;
+    mli::mem::Block* block_;
+};
+
+template <typename T>
+class Tensor {
+public:
+    Tensor(const std::vector<std::size_t>& shape, DeviceType device = DeviceType::HOST,
+           TensorDataType tensor_data_type = DEFAULT_TENSOR_DATA_TYPE)
+        : shape_(shape), size_(1), device_(device) {
+        for (std::size_t d : shape_) size_ *= d;
+        data_ = std::make_shared<TensorData<T>>(size_, device, tensor_data_type);
+    }
+    Tensor(const Tensor&) = default;             // shallow: both tensors see the same memory
+    Tensor& operator=(const Tensor&) = default;
+    ~Tensor() = default;
+
+    const std::vector<std::size_t>& shape() const { return shape_; }
+    DeviceType device() const { return device_; }
+    // Fetch the pointer once outside hot loops (the async flavour may wait on an event here).
+    T* data() { return data_->data(); }
+    const T* data() const { return data_->data(); }
+    void copy_from(const Tensor& other) { data_->copy_from(*other.data_); }
+    void copy_range_from(const Tensor& other, std::size_t first, std::size_t count) {
+        data_->copy_range_from(*other.data_, first, count);
+    }
+    std::size_t get_total_size() const { return size_; }
+
+private:
+    std::vector<std::size_t> shape_;
+    std::size_t size_;
+    DeviceType device_;
+    std::shared_ptr<TensorData<T>> data_;
+};
+
+typedef Tensor<float> TensorFloat;
+typedef Tensor<int> TensorInt;
+typedef Tensor<float*> TensorFloatPoint;

@@ -1,0 +1,220 @@
+// extern "C" engine sessions (include/mli_engine.h): the reference's engine loops in resumable form, so a
+// host in another language -- or bench.py -- can step them and interleave the multi-GPU token gather.
+#include <cstring>
+#include <iterator>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "constants.h"
+#include "inference_model.h"
+#include "inferencer.h"
+#include "mli_engine.h"
+#include "runtime.h"
+#include "throughput_counter.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+TensorFloat upload(const float* host, std::vector<size_t> shape) {
+    TensorFloat staging(shape, DeviceType::HOST);
+    std::memcpy(staging.data(), host, staging.get_total_size() * sizeof(float));
+    TensorFloat device(shape, DeviceType::DEVICE);
+    device.copy_from(staging);
+    return device;
+}
+
+}  // namespace
+
+struct mli_engine {
+    mli_engine_config cfg;
+    TensorFloat emb_table, pos_table;
+    ItemStorage item_storage;
+    ProcessingStorage processing_storage;
+    std::unique_ptr<InferenceModel> naive_model;
+    std::unique_ptr<PagedAttentionInferenceModel> paged_model;
+    std::unique_ptr<PagedAttentionCublasInferenceModel> gemm_model;
+    std::unique_ptr<MemoryBlockManager> pool;
+    std::unique_ptr<PagedAttentionsManager> pages;
+    TensorInt inp_device, inp_host, lengths_device, lengths_host, new_idx_device, new_idx_host;
+    TensorInt result_device, result_host;
+    bool started = false;
+    int n_new_items = 0;
+    long long iterations = 0;
+    GemmHandle handle;
+
+    mli_engine(const mli_engine_config& c, const float* emb, const float* pos, const float* wk, const float* wq,
+               const float* wv)
+        : cfg(c),
+          emb_table(upload(emb, {(size_t)c.n_vocab, (size_t)c.emb_dim})),
+          pos_table(upload(pos, {(size_t)c.n_sequence, (size_t)c.emb_dim})),
+          inp_device({(size_t)c.n_batch, (size_t)c.n_sequence}, DeviceType::DEVICE),
+          inp_host({(size_t)c.n_batch, (size_t)c.n_sequence}, DeviceType::HOST),
+          lengths_device({(size_t)c.n_batch}, DeviceType::DEVICE), lengths_host({(size_t)c.n_batch}, DeviceType::HOST),
+          new_idx_device({(size_t)c.n_batch}, DeviceType::DEVICE), new_idx_host({(size_t)c.n_batch}, DeviceType::HOST),
+          result_device(result_shape(c), DeviceType::DEVICE), result_host(result_shape(c), DeviceType::HOST) {
+        const size_t B = c.n_batch, S = c.n_sequence, D = c.emb_dim, V = c.n_vocab;
+        TensorFloat dk = upload(wk, {D, D}), dq = upload(wq, {D, D}), dv = upload(wv, {D, D});
+        if (c.kind == MLI_ENGINE_CONTIGUOUS) {
+            naive_model = std::make_unique<InferenceModel>(
+                SelfAttentionLayer(std::move(dk), std::move(dq), std::move(dv), B, D, S), EncoderLayer(),
+                DecoderLayer(B, V), B, S, D);
+        } else {
+            pool = std::make_unique<MemoryBlockManager>(c.n_blocks, (size_t)PAGE_BLOCK_SIZE * 3 * D);
+            pages = std::make_unique<PagedAttentionsManager>(B, S, D);
+            if (c.kind == MLI_ENGINE_PAGED)
+                paged_model = std::make_unique<PagedAttentionInferenceModel>(
+                    PagedAttentionLayer(std::move(dk), std::move(dq), std::move(dv), B, D, S), PagedEncoderLayer(),
+                    PagedDecoderLayer(B, V), B, S, D, c.n_forward_rounds);
+            else
+                gemm_model = std::make_unique<PagedAttentionCublasInferenceModel>(
+                    PagedAttentionCublasLayer(std::move(dk), std::move(dq), std::move(dv), B, D, S),
+                    PagedEncoderLayer(), PagedCublasDecoderLayer(B, V), B, S, D, c.n_forward_rounds);
+        }
+        std::memset(lengths_host.data(), 0, B * sizeof(int));
+        std::memset(inp_host.data(), 0, B * S * sizeof(int));
+        inp_device.copy_from(inp_host);
+        lengths_device.copy_from(lengths_host);
+    }
+
+    static std::vector<size_t> result_shape(const mli_engine_config& c) {
+        if (c.kind == MLI_ENGINE_CONTIGUOUS) return {(size_t)c.n_batch};
+        return {(size_t)c.n_batch, (size_t)c.n_forward_rounds};
+    }
+
+    bool paged() const { return cfg.kind != MLI_ENGINE_CONTIGUOUS; }
+
+    void insert(const std::vector<int>& free_slots) {
+        if (paged()) {
+            n_new_items = (int)insert_new_items(inp_device, inp_host, lengths_device, lengths_host, new_idx_device,
+                                                new_idx_host, item_storage, processing_storage, *pool, *pages,
+                                                cfg.n_forward_rounds).size();
+        } else {
+            n_new_items = insert_new_items(free_slots, inp_device, inp_host, lengths_device, lengths_host,
+                                           new_idx_device, new_idx_host, item_storage, processing_storage);
+        }
+    }
+
+    void start() {
+        set_reference_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
+        get_global_throughput_counter().reset();
+        get_global_throughput_counter().start_record();
+        std::vector<int> all(cfg.n_batch);
+        std::iota(all.begin(), all.end(), 0);
+        insert(all);
+        started = true;
+    }
+
+    bool done() { return is_done(item_storage, processing_storage); }
+
+    void step() {
+        if (!started) start();
+        if (done()) return;
+        if (cfg.kind == MLI_ENGINE_CONTIGUOUS)
+            naive_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
+                                 pos_table);
+        else if (cfg.kind == MLI_ENGINE_PAGED)
+            paged_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
+                                 pos_table, pages->get_page_table_device());
+        else
+            gemm_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
+                                pos_table, pages->get_page_table_device(), handle);
+        std::vector<int> free_slots =
+            process_decoder_result(result_device, result_host, item_storage, processing_storage, cfg.n_sequence);
+        if (paged())
+            allocate_or_free_memory_blocks_if_needed(*pages, *pool, processing_storage, item_storage, free_slots,
+                                                     cfg.n_forward_rounds);
+        insert(free_slots);
+        ++iterations;
+    }
+
+    void fill(mli_engine_stats* s) {
+        s->total_tokens = get_global_throughput_counter().total_tokens();
+        s->seconds = get_global_throughput_counter().seconds();
+        s->iterations = iterations;
+        s->finished = item_storage.finish_count();
+        s->waiting = item_storage.new_count();
+        s->in_flight = processing_storage.size();
+    }
+};
+
+#define MLI_GUARD(body)                                  \
+    try {                                                \
+        body;                                            \
+        return 0;                                        \
+    } catch (const std::exception& e) {                  \
+        g_last_error = e.what();                         \
+        return -1;                                       \
+    } catch (...) {                                      \
+        g_last_error = "unknown C++ exception";          \
+        return -1;                                       \
+    }
+
+extern "C" {
+
+const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
+
+int mli_engine_create(const mli_engine_config* c, const float* emb_table, const float* pos_table, const float* wk,
+                      const float* wq, const float* wv, mli_engine** out) {
+    if (!c || !out || !emb_table || !pos_table || !wk || !wq || !wv) { g_last_error = "null argument"; return -1; }
+    if (c->kind < 0 || c->kind > 2 || c->n_batch <= 0 || c->n_sequence <= 0 || c->emb_dim <= 0 || c->emb_dim % 4 ||
+        c->n_vocab <= EOF_TOKEN_ID ||
+        (c->kind != MLI_ENGINE_CONTIGUOUS && (c->n_sequence % PAGE_BLOCK_SIZE || c->n_blocks <= 0 ||
+                                              c->n_forward_rounds < 1 || c->n_forward_rounds > PAGE_BLOCK_SIZE)) ||
+        (c->kind == MLI_ENGINE_CONTIGUOUS && c->n_sequence % 4)) {
+        g_last_error = "invalid engine configuration";
+        return -1;
+    }
+    MLI_GUARD({
+        mli::runtime::use_device(c->device);
+        *out = new mli_engine(*c, emb_table, pos_table, wk, wq, wv);
+    })
+}
+
+void mli_engine_destroy(mli_engine* e) { delete e; }
+
+int mli_engine_add_item(mli_engine* e, int id, const int* tokens, int n_tokens) {
+    if (!e || !tokens || n_tokens <= 0 || n_tokens + 1 > e->cfg.n_sequence) { g_last_error = "bad item"; return -1; }
+    MLI_GUARD(e->item_storage.add_new_item(std::make_pair(id, std::vector<int>(tokens, tokens + n_tokens))))
+}
+
+int mli_engine_step(mli_engine* e, int* done) {
+    MLI_GUARD({
+        mli::runtime::use_device(e->cfg.device);
+        e->step();
+        if (done) *done = e->done() ? 1 : 0;
+    })
+}
+
+int mli_engine_run(mli_engine* e, mli_engine_stats* stats) {
+    MLI_GUARD({
+        mli::runtime::use_device(e->cfg.device);
+        if (!e->started) e->start();
+        while (!e->done()) e->step();
+        if (stats) e->fill(stats);
+    })
+}
+
+int mli_engine_get_stats(mli_engine* e, mli_engine_stats* stats) { MLI_GUARD(e->fill(stats)) }
+
+int mli_engine_decoder_result(mli_engine* e, void** device_ptr, int* count) {
+    MLI_GUARD({
+        *device_ptr = e->result_device.data();
+        *count = (int)e->result_device.get_total_size();
+    })
+}
+
+int mli_engine_get_finished(mli_engine* e, int index, int* id, int* tokens, int capacity, int* n_tokens) {
+    MLI_GUARD({
+        const auto& items = e->item_storage.get_finished_items();
+        if (index < 0 || index >= (int)items.size()) throw std::out_of_range("finished item index");
+        auto it = std::next(items.begin(), index);
+        *id = it->first;
+        *n_tokens = (int)it->second.size();
+        if (tokens) std::memcpy(tokens, it->second.data(), sizeof(int) * std::min<size_t>(capacity, it->second.size()));
+    })
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+#include "inferencer.h"
+
+#include <numeric>
+#include <vector>
+
+#include "runtime.h"
+#include "throughput_counter.h"
+
+namespace {
+
+// Host/device pairs every engine loop needs; HOST tensors are pinned.
+struct LoopTensors {
+    TensorInt inp_device, inp_host;
+    TensorInt lengths_device, lengths_host;
+    TensorInt new_items_indices_device, new_items_indices_host;
+    TensorInt decoder_result_device, decoder_result_host;
+
+    LoopTensors(size_t n_batch, size_t n_sequence, std::vector<size_t> result_shape)
+        : inp_device({n_batch, n_sequence}, DeviceType::DEVICE), inp_host({n_batch, n_sequence}, DeviceType::HOST),
+          lengths_device({n_batch}, DeviceType::DEVICE), lengths_host({n_batch}, DeviceType::HOST),
+          new_items_indices_device({n_batch}, DeviceType::DEVICE), new_items_indices_host({n_batch}, DeviceType::HOST),
+          decoder_result_device(result_shape, DeviceType::DEVICE), decoder_result_host(result_shape, DeviceType::HOST) {}
+};
+
+struct Range {  // roctx range, closed on scope exit
+    explicit Range(const char* name) { mli::runtime::range_push(name); }
+    ~Range() { mli::runtime::range_pop(); }
+};
+
+// Shared body of the two paged engines; `forward` hides the model type (and its GemmHandle).
+template <typename Forward>
+void run_paged_engine(ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                      MemoryBlockManager& memory_block_manager, PagedAttentionsManager& paged_attention_manager,
+                      size_t n_batch_size, size_t n_sequence, int n_forward_rounds, Forward&& forward) {
+    LoopTensors t(n_batch_size, n_sequence, {n_batch_size, static_cast<size_t>(n_forward_rounds)});
+    get_global_throughput_counter().start_record();
+    std::vector<int> new_item_indices;
+    {
+        Range r("insert_new_items");
+        new_item_indices = insert_new_items(t.inp_device, t.inp_host, t.lengths_device, t.lengths_host,
+                                            t.new_items_indices_device, t.new_items_indices_host, item_storage,
+                                            processing_storage, memory_block_manager, paged_attention_manager,
+                                            n_forward_rounds);
+    }
+    while (!is_done(item_storage, processing_storage)) {
+        {
+            Range r("forward");
+            forward(t, static_cast<int>(new_item_indices.size()));
+        }
+        std::vector<int> finished_indices;
+        {
+            Range r("process_decoder_result");
+            finished_indices = process_decoder_result(t.decoder_result_device, t.decoder_result_host, item_storage,
+                                                      processing_storage, static_cast<int>(n_sequence));
+        }
+        {
+            Range r("allocate_or_free_memory_blocks_if_needed");
+            allocate_or_free_memory_blocks_if_needed(paged_attention_manager, memory_block_manager,
+                                                     processing_storage, item_storage, finished_indices,
+                                                     n_forward_rounds);
+        }
+        {
+            Range r("insert_new_items");
+            new_item_indices = insert_new_items(t.inp_device, t.inp_host, t.lengths_device, t.lengths_host,
+                                                t.new_items_indices_device, t.new_items_indices_host, item_storage,
+                                                processing_storage, memory_block_manager, paged_attention_manager,
+                                                n_forward_rounds);
+        }
+    }
+    get_global_throughput_counter().print_throughput();
+}
+
+}  // namespace
+
+void start_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
+                            ProcessingStorage& processing_storage, InferenceModel& inference_model,
+                            size_t n_batch_size, size_t n_sequence) {
+    LoopTensors t(n_batch_size, n_sequence, {n_batch_size});
+    std::vector<int> free_slots(n_batch_size);
+    std::iota(free_slots.begin(), free_slots.end(), 0);  // every slot starts empty
+    int n_new_items = insert_new_items(free_slots, t.inp_device, t.inp_host, t.lengths_device, t.lengths_host,
+                                       t.new_items_indices_device, t.new_items_indices_host, item_storage,
+                                       processing_storage);
+    while (!is_done(item_storage, processing_storage)) {
+        inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device, t.decoder_result_device,
+                                n_new_items, emb_table, pos_table);
+        free_slots = process_decoder_result(t.decoder_result_device, t.decoder_result_host, item_storage,
+                                            processing_storage, static_cast<int>(n_sequence));
+        n_new_items = insert_new_items(free_slots, t.inp_device, t.inp_host, t.lengths_device, t.lengths_host,
+                                       t.new_items_indices_device, t.new_items_indices_host, item_storage,
+                                       processing_storage);
+    }
+}
+
+void start_paged_attention_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table,
+                                            ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                            MemoryBlockManager& memory_block_manager,
+                                            PagedAttentionsManager& paged_attention_manager,
+                                            PagedAttentionInferenceModel& inference_model, size_t n_batch_size,
+                                            size_t n_sequence, int n_forward_rounds) {
+    run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
+                     n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
+                         inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
+                                                 t.decoder_result_device, n_new_items, emb_table, pos_table,
+                                                 paged_attention_manager.get_page_table_device());
+                     });
+}
+
+void start_paged_attention_cublas_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table,
+                                                   ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                                   MemoryBlockManager& memory_block_manager,
+                                                   PagedAttentionsManager& paged_attention_manager,
+                                                   PagedAttentionCublasInferenceModel& inference_model,
+                                                   size_t n_batch_size, size_t n_sequence, int n_forward_rounds) {
+    GemmHandle handle;  // the reference creates / destroys a cublasHandle_t here; nothing to create for MFMA
+    run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
+                     n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
+                         inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
+                                                 t.decoder_result_device, n_new_items, emb_table, pos_table,
+                                                 paged_attention_manager.get_page_table_device(), handle);
+                     });
+}

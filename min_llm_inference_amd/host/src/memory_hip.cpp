@@ -1,0 +1,171 @@
+// HIP implementation of the Tensor memory backend (memory.h) and of the per-thread runtime context.
+//   sync  flavour: hipMalloc / hipHostMalloc / hipMemcpy                      (reference tensor.hpp:272-322)
+//   async flavour: hipMallocAsync / hipMemcpyAsync on one transfer stream per device plus a readiness
+//                  event per block that pointer() waits on                      (reference tensor.hpp:182-269)
+#include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
+
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+
+#include "memory.h"
+#include "runtime.h"
+#include "utils.h"
+
+void hip_check(int status, const char* file, int line) {
+    if (status != 0) {
+        const char* msg = status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "invalid argument to the mli C ABI";
+        std::printf("[HIP ERROR] at file %s:%d:\n%s (%d)\n", file, line, msg, status);
+        throw std::runtime_error("Hip Failure");
+    }
+}
+
+void hip_check_last(const char* file, int line) {
+#ifdef USE_SYNC_HIP_CHECK
+    hip_check(static_cast<int>(hipDeviceSynchronize()), file, line);
+#endif
+    hip_check(static_cast<int>(hipGetLastError()), file, line);
+}
+
+namespace mli {
+namespace runtime {
+
+namespace {
+thread_local void* t_stream = nullptr;
+}
+
+void use_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
+
+int current_device() {
+    int d = 0;
+    HIP_CHECK(hipGetDevice(&d));
+    return d;
+}
+
+void set_compute_stream(void* stream) { t_stream = stream; }
+void* compute_stream() { return t_stream; }
+
+void synchronize() {
+    if (t_stream) HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(t_stream)));
+    else HIP_CHECK(hipDeviceSynchronize());
+}
+
+void range_push(const char* name) { roctxRangePushA(name); }
+void range_pop() { roctxRangePop(); }
+
+}  // namespace runtime
+
+namespace mem {
+
+struct Block {
+    void* ptr = nullptr;
+    std::size_t bytes = 0;
+    Space space = Space::Host;
+    Mode mode = Mode::Sync;
+    int device = 0;
+    hipEvent_t ready = nullptr;  // async flavour: recorded after the last operation that touched ptr
+    bool pending = false;
+};
+
+namespace {
+
+// One transfer stream per device for the async flavour (created on first use, never destroyed --
+// the reference leaks its stream the same way, tensor.hpp:123-130).
+hipStream_t transfer_stream(int device) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreate(&s));
+    streams[device] = s;
+    return s;
+}
+
+void mark_pending(Block* b) {
+    if (b->ready == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(b->ready, transfer_stream(b->device)));
+    b->pending = true;
+}
+
+void wait_ready(Block* b) {
+    if (b->pending) {
+        HIP_CHECK(hipEventSynchronize(b->ready));
+        b->pending = false;
+    }
+}
+
+hipMemcpyKind kind_of(Space dst, Space src) {
+    if (dst == Space::Host) return src == Space::Host ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+    return src == Space::Host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+}
+
+}  // namespace
+
+Block* acquire(std::size_t bytes, Space space, Mode mode) {
+    Block* b = new Block;
+    b->bytes = bytes;
+    b->space = space;
+    b->mode = mode;
+    b->device = runtime::current_device();
+    const std::size_t n = bytes ? bytes : 1;
+    try {
+        if (space == Space::Host) {
+            HIP_CHECK(hipHostMalloc(&b->ptr, n, hipHostMallocDefault));  // pinned, as the reference's cudaHostAlloc
+        } else if (mode == Mode::Sync) {
+            HIP_CHECK(hipMalloc(&b->ptr, n));
+        } else {
+            HIP_CHECK(hipMallocAsync(&b->ptr, n, transfer_stream(b->device)));
+            mark_pending(b);
+        }
+    } catch (...) {
+        delete b;
+        throw;
+    }
+    return b;
+}
+
+void release(Block* b) noexcept {
+    if (b == nullptr) return;
+    if (b->space == Space::Host) {
+        if (b->pending) (void)hipEventSynchronize(b->ready);
+        (void)hipHostFree(b->ptr);
+    } else if (b->mode == Mode::Sync) {
+        (void)hipFree(b->ptr);
+    } else {
+        (void)hipFreeAsync(b->ptr, transfer_stream(b->device));
+    }
+    if (b->ready) (void)hipEventDestroy(b->ready);
+    delete b;
+}
+
+void* pointer(Block* b) {
+    wait_ready(b);
+    return b->ptr;
+}
+
+void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t bytes) {
+    if (bytes == 0) return;
+    Block* s = const_cast<Block*>(src);
+    const hipMemcpyKind kind = kind_of(dst->space, src->space);
+    char* d = static_cast<char*>(dst->ptr) + byte_offset;
+    const char* f = static_cast<const char*>(s->ptr) + byte_offset;
+    if (dst->mode == Mode::Sync) {
+        HIP_CHECK(hipMemcpy(d, f, bytes, kind));
+    } else {
+        wait_ready(s);
+        wait_ready(dst);
+        HIP_CHECK(hipMemcpyAsync(d, f, bytes, kind, transfer_stream(dst->device)));
+        mark_pending(dst);
+    }
+}
+
+Space space_of(const Block* b) { return b->space; }
+Mode mode_of(const Block* b) { return b->mode; }
+std::size_t size_of(const Block* b) { return b->bytes; }
+
+}  // namespace mem
+}  // namespace mli

@@ -1,0 +1,50 @@
+// TEST DOUBLE for the Tensor memory backend (min_llm_inference_amd/host/include/memory.h): plain malloc /
+// memcpy so that the host scheduler can be unit-tested in a container without a GPU.  Linked only into
+// tests/cpp binaries -- never into libmli_hip.so.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "memory.h"
+#include "utils.h"
+
+void hip_check(int status, const char* file, int line) {
+    if (status != 0) {
+        std::printf("[HIP ERROR] at file %s:%d: status %d\n", file, line, status);
+        throw std::runtime_error("Hip Failure");
+    }
+}
+void hip_check_last(const char*, int) {}
+
+namespace mli {
+namespace mem {
+
+struct Block {
+    void* ptr;
+    std::size_t bytes;
+    Space space;
+    Mode mode;
+};
+
+Block* acquire(std::size_t bytes, Space space, Mode mode) {
+    Block* b = new Block{std::malloc(bytes ? bytes : 1), bytes, space, mode};
+    if (!b->ptr) throw std::bad_alloc();
+    return b;
+}
+void release(Block* b) noexcept {
+    if (!b) return;
+    std::free(b->ptr);
+    delete b;
+}
+void* pointer(Block* b) { return b->ptr; }
+void copy(Block* dst, const Block* src, std::size_t off, std::size_t bytes) {
+    if (off + bytes > dst->bytes || off + bytes > src->bytes) throw std::runtime_error("copy out of range");
+    std::memcpy(static_cast<char*>(dst->ptr) + off, static_cast<const char*>(src->ptr) + off, bytes);
+}
+Space space_of(const Block* b) { return b->space; }
+Mode mode_of(const Block* b) { return b->mode; }
+std::size_t size_of(const Block* b) { return b->bytes; }
+
+}  // namespace mem
+}  // namespace mli
