@@ -179,7 +179,6 @@ def cpu_baseline(wl, budget_s=12.0):
     same workload, contiguous layout (the reference has no CPU paged path), decode step only (n_new = 0)."""
     import oracle
     D, S = wl.D, wl.S
-    rows = 8
     rng = np.random.default_rng(1)
 
     def run(n):
@@ -196,13 +195,29 @@ def cpu_baseline(wl, budget_s=12.0):
         oracle.self_attention_inference_host(inp, L, w[0], w[1], w[2], idx, kt, v, q, s, o, 0)
         return time.perf_counter() - t0, int((L > 0).sum())
 
-    t, live = run(rows)
-    per_row = t / max(live, 1)
-    n = int(min(wl.B, max(rows, budget_s / max(per_row, 1e-9)), 4e9 // (3 * S * D * 4)))
-    t, live = run(n)
-    return {"value": live / t, "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of {wl.B} rows of the same workload (contiguous layout, decode step only), "
-                      f"{t:.1f} s single-threaded oracle_cpu.c"}
+    n = int(min(wl.B, 4e9 // (3 * S * D * 4)))  # row sample bounded by ~4 GB of host memory
+    total_t, total_tok, reps = 0.0, 0, 0
+    while total_t < budget_s and reps < 50:      # repeat the decode step over the sample until ~budget_s of CPU work
+        t, live = run(n)
+        total_t += t
+        total_tok += live
+        reps += 1
+    return {"value": total_tok / total_t, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} decode steps over {n} of {wl.B} rows of the same workload (contiguous layout, "
+                      f"n_new=0), {total_t:.1f} s single-threaded oracle_cpu.c"}
+
+
+def pmc_traffic(workload, which, layout):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this command
+    (profiles/pmc_<workload>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE).  bench.py cannot
+    run the counter passes on itself, so this is null when no summary for the workload is committed."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
+    if not os.path.exists(path):
+        return None, None
+    kernels = json.load(open(path))["kernels"]
+    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial"}[which]
+    hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k]
+    return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
 
 def main():
@@ -229,12 +244,12 @@ def main():
 
     cfg_index = sorted(WORKLOADS).index(args.workload) + 1
     wl = Workload(args.workload, dev, 0x5EED0000 + cfg_index * 16 + rank, headroom=args.steps + args.warmup + 8)
-    tokens_all = torch.empty(world * wl.B, dtype=torch.int32, device=dev) if world > 1 else None
+    from min_llm_inference_amd.sharding import TokenGather
+    gather = TokenGather(wl.B, world, dev)
 
     def step():
         wl.step()
-        if world > 1:  # the path's only exchange: generated token ids (4 KiB per rank at B=1024)
-            dist.all_gather_into_tensor(tokens_all, wl.decoder_result.view(-1))
+        gather(wl.decoder_result)  # the path's only exchange: generated token ids (4 KiB per rank at B=1024)
 
     for _ in range(args.warmup):
         step()
@@ -294,9 +309,10 @@ def main():
         dom = max(key_of, key=lambda k: times[key_of[k]])
         ms = times[key_of[dom]]
         achieved = alg[dom] / (ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload, dom, wl.layout)
         out["roofline"] = {
             "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms,
             "kernel_ms": times,
             "step_algorithmic_bytes": alg["step"],

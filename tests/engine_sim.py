@@ -26,58 +26,75 @@ def make_items(seed, n_items, min_len, max_len, eof_token=1023):
             for i in range(n_items)]
 
 
-def run_cpu_engine(oracle, model, items, n_batch, n_sequence):
-    """Returns {item id: all tokens (prompt + generated)} and the number of iterations."""
-    D = model["wk"].shape[0]
-    V = model["emb_table"].shape[0]
-    B, S = n_batch, n_sequence
-    inp = np.zeros((B, S), np.int32)
-    lengths = np.zeros((B,), np.int32)
-    inp_emb = np.zeros((B, S, D), np.float32)
-    kt = np.zeros((B, D, S), np.float32)
-    v = np.zeros((B, S, D), np.float32)
-    q = np.zeros((B, D), np.float32)
-    qkt = np.zeros((B, S), np.float32)
-    att = np.zeros((B, D), np.float32)
-    score = np.zeros((B, V), np.float32)
-    result = np.zeros((B,), np.int32)
-    new_idx = np.zeros((B,), np.int32)
-    queue = [(i, list(map(int, t))) for i, t in items]
-    processing, finished = {}, {}
+class CpuEngine:
+    """Steppable form: one call to step() = one iteration of start_inference_engine's loop."""
 
-    def insert(free_slots):
+    def __init__(self, oracle, model, items, n_batch, n_sequence):
+        self.o, self.m = oracle, model
+        D = model["wk"].shape[0]
+        V = model["emb_table"].shape[0]
+        B, S = n_batch, n_sequence
+        self.B, self.S = B, S
+        self.inp = np.zeros((B, S), np.int32)
+        self.lengths = np.zeros((B,), np.int32)
+        self.inp_emb = np.zeros((B, S, D), np.float32)
+        self.kt = np.zeros((B, D, S), np.float32)
+        self.v = np.zeros((B, S, D), np.float32)
+        self.q = np.zeros((B, D), np.float32)
+        self.qkt = np.zeros((B, S), np.float32)
+        self.att = np.zeros((B, D), np.float32)
+        self.score = np.zeros((B, V), np.float32)
+        self.result = np.full((B,), -1, np.int32)
+        self.new_idx = np.zeros((B,), np.int32)
+        self.queue = [(i, list(map(int, t))) for i, t in items]
+        self.processing, self.finished = {}, {}
+        self.iterations = 0
+        self.n_new = self._insert(list(range(B)))
+
+    def _insert(self, free_slots):
         n_new = 0
         for k, slot in enumerate(free_slots):
-            new_idx[k] = slot
-            if queue:
-                item_id, toks = queue.pop(0)
-                lengths[slot] = len(toks)
-                inp[slot, :len(toks)] = toks
-                processing[slot] = (item_id, toks)
+            self.new_idx[k] = slot
+            if self.queue:
+                item_id, toks = self.queue.pop(0)
+                self.lengths[slot] = len(toks)
+                self.inp[slot, :len(toks)] = toks
+                self.processing[slot] = (item_id, toks)
                 n_new += 1
             else:
-                lengths[slot] = 0
+                self.lengths[slot] = 0
         return n_new
 
-    n_new = insert(list(range(B)))
-    iterations = 0
-    while processing or queue:
-        oracle.inference_optimized_encoder_host(model["emb_table"], model["pos_table"], inp, inp_emb, lengths, new_idx, n_new)
-        oracle.self_attention_inference_host(inp_emb, lengths, model["wk"], model["wq"], model["wv"], new_idx, kt, v, q,
-                                             qkt, att, n_new)
-        oracle.decoder_host(att, model["emb_table"], score, model["pos_table"], inp_emb, lengths, result)
+    def done(self):
+        return not (self.processing or self.queue)
+
+    def step(self):
+        o, m = self.o, self.m
+        o.inference_optimized_encoder_host(m["emb_table"], m["pos_table"], self.inp, self.inp_emb, self.lengths,
+                                           self.new_idx, self.n_new)
+        o.self_attention_inference_host(self.inp_emb, self.lengths, m["wk"], m["wq"], m["wv"], self.new_idx, self.kt,
+                                        self.v, self.q, self.qkt, self.att, self.n_new)
+        o.decoder_host(self.att, m["emb_table"], self.score, m["pos_table"], self.inp_emb, self.lengths, self.result)
         free_slots = []
-        for b in range(B):
-            tok = int(result[b])
-            if tok == oracle.EMPTY_ROW_TOKEN_ID:
+        for b in range(self.B):
+            tok = int(self.result[b])
+            if tok == o.EMPTY_ROW_TOKEN_ID:
                 free_slots.append(b)
                 continue
-            item_id, toks = processing[b]
+            item_id, toks = self.processing[b]
             toks.append(tok)
-            if len(toks) >= S or tok == oracle.EOF_TOKEN_ID:
-                finished[item_id] = np.asarray(toks, np.int32)
-                del processing[b]
+            if len(toks) >= self.S or tok == o.EOF_TOKEN_ID:
+                self.finished[item_id] = np.asarray(toks, np.int32)
+                del self.processing[b]
                 free_slots.append(b)
-        n_new = insert(free_slots)
-        iterations += 1
-    return finished, iterations
+        self.n_new = self._insert(free_slots)
+        self.iterations += 1
+        return self.result.copy()
+
+
+def run_cpu_engine(oracle, model, items, n_batch, n_sequence):
+    """Returns {item id: all tokens (prompt + generated)} and the number of iterations."""
+    e = CpuEngine(oracle, model, items, n_batch, n_sequence)
+    while not e.done():
+        e.step()
+    return e.finished, e.iterations
