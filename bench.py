@@ -42,9 +42,13 @@ class Workload:
     """Synthetic decode state for one GPU (weights U(-1,1)/sqrt(D), lengths U[S/4, 3S/4],
     pages drawn from a shuffled pool)."""
 
-    def __init__(self, name, dev, seed, headroom):
+    def __init__(self, name, dev, seed, headroom, dtype="f32"):
         self.name = name
         self.layout, self.B, self.D, self.S = WORKLOADS[name]
+        self.dtype = dtype
+        self.esize = 2 if dtype == "bf16" else 4  # bytes per KV / weight element
+        if dtype == "bf16" and self.layout != "paged":
+            raise SystemExit("bf16 is implemented for the paged layout (BASELINE config 4)")
         B, D, S = self.B, self.D, self.S
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
@@ -61,6 +65,8 @@ class Workload:
 
         sc = 1.0 / np.sqrt(D)
         self.wk, self.wq, self.wv = (u(D, D, scale=sc) for _ in range(3))
+        if dtype == "bf16":
+            self.wk, self.wq, self.wv = (w.to(torch.bfloat16) for w in (self.wk, self.wq, self.wv))
         self.emb_table = u(N_VOCAB, D)
         self.emb_table[ops.EOF_TOKEN_ID] = 0  # EOF never wins the argmax: the batch stays full while timing
         self.wpe = u(S, D)
@@ -75,20 +81,21 @@ class Workload:
             per_row = [-(-(int(L) + headroom + 2) // PAGE) for L in lengths]
             total = sum(per_row)
             block = PAGE * 3 * D
-            self.pool = torch.empty(total * block, device=dev)
+            self.pool = torch.empty(total * block, device=dev,
+                                    dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
             chunk = 1 << 28
             for o in range(0, self.pool.numel(), chunk):  # K/V/x contents: U(-1,1)
                 n = min(chunk, self.pool.numel() - o)
-                self.pool[o:o + n] = u(n)
+                self.pool[o:o + n] = u(n).to(self.pool.dtype)
             order = rng.permutation(total)
             table = np.zeros((B, W), np.int64)
             cur = 0
             base = self.pool.data_ptr()
             for b in range(B):
-                table[b, :per_row[b]] = base + 4 * block * order[cur:cur + per_row[b]].astype(np.int64)
+                table[b, :per_row[b]] = base + self.esize * block * order[cur:cur + per_row[b]].astype(np.int64)
                 cur += per_row[b]
             self.page_table = torch.from_numpy(table).to(dev)
-            self.kv_bytes_resident = self.pool.numel() * 4
+            self.kv_bytes_resident = self.pool.numel() * self.esize
         else:
             self.inp_embedding = u(B, S, D)
             self.kt_cache = u(B, D, S)
@@ -97,7 +104,10 @@ class Workload:
         torch.cuda.synchronize()
 
     def attention(self):
-        if self.layout == "paged":
+        if self.dtype == "bf16":
+            ops.paged_attention_bf16(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx,
+                                     self.q_output, self.qkt_output, self.attention_result, 0, self.S)
+        elif self.layout == "paged":
             ops.paged_attention(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx, self.q_output,
                                 self.qkt_output, self.attention_result, 0, self.S)
         else:
@@ -106,7 +116,11 @@ class Workload:
                                          self.attention_result, 0)
 
     def decoder(self):
-        if self.layout == "paged":
+        if self.dtype == "bf16":
+            ops.launch_paged_attention_decoder_multi_rounds_bf16(self.attention_result, self.emb_table, self.emb_score,
+                                                                 self.wpe, self.page_table, self.lengths,
+                                                                 self.decoder_result, 0)
+        elif self.layout == "paged":
             ops.launch_paged_attention_decoder_multi_rounds(self.attention_result, self.emb_table, self.emb_score,
                                                             self.wpe, self.page_table, self.lengths,
                                                             self.decoder_result, 0)
@@ -121,6 +135,15 @@ class Workload:
     # ---- the individual kernels, for the roofline pass ------------------------------------
     def kernels(self):
         w = self
+        if self.dtype == "bf16":
+            return {
+                "get_latest_k_q_v_paged_bf16 (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention_bf16(
+                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
+                "qkt_paged_bf16": lambda: ops.launch_qkt_paged_attention_bf16(w.q_output, w.page_table, w.lengths, w.qkt_output),
+                "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
+                "softmax_v_paged_bf16": lambda: ops.launch_softmax_v_paged_attention_bf16(w.qkt_output, w.page_table,
+                                                                                          w.attention_result, w.lengths),
+            }
         if self.layout == "paged":
             return {
                 "get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention(
@@ -139,16 +162,16 @@ class Workload:
         }
 
     def algorithmic_bytes(self, lengths):
-        """Per-launch algorithmic HBM bytes (DESIGN.md 'Roofline accounting'); e = 4 bytes (fp32)."""
+        """Per-launch algorithmic HBM bytes (DESIGN.md 'Roofline accounting'); e = bytes per KV/weight element."""
         L = lengths.astype(np.int64)
-        B, D = self.B, self.D
+        B, D, e = self.B, self.D, self.esize
         live = int((L > 0).sum())
         ptrs = int((8 * -(-L // PAGE)).sum()) if self.layout == "paged" else 0
-        kv_one = int(L.sum()) * D * 4
+        kv_one = int(L.sum()) * D * e
         qkt = kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4       # K + q in, scores out
         sv = kv_one + int(L.sum()) * 4 + live * D * 4 + ptrs + B * 4        # V + probs in, result out
-        latest = live * D * 4 * 4 + 3 * D * D * 4 + B * 4 + (8 * live if self.layout == "paged" else 0)
-        step = (2 * kv_one + live * (3 * D * 4 + D * 4) + 3 * D * D * 4 + B * 4 + ptrs)  # SURVEY 8(d)
+        latest = live * D * (3 * e + 4) + 3 * D * D * e + B * 4 + (8 * live if self.layout == "paged" else 0)
+        step = (2 * kv_one + live * (3 * D * e + D * 4) + 3 * D * D * e + B * 4 + ptrs)  # SURVEY 8(d)
         return {"qkt": qkt, "softmax_v": sv, "get_latest": latest, "step": step}
 
 
@@ -203,15 +226,16 @@ def cpu_baseline(wl, budget_s=12.0):
         total_tok += live
         reps += 1
     return {"value": total_tok / total_t, "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} decode steps over {n} of {wl.B} rows of the same workload (contiguous layout, "
-                      f"n_new=0), {total_t:.1f} s single-threaded oracle_cpu.c"}
+            "sample": f"{reps} decode steps over {n} of {wl.B} rows of the same workload shape (contiguous layout, "
+                      f"n_new=0, fp32 -- the reference's CPU path has no paged or bf16 form), {total_t:.1f} s "
+                      f"single-threaded oracle_cpu.c"}
 
 
-def pmc_traffic(workload, which, layout):
+def pmc_traffic(workload, which, layout, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this command
     (profiles/pmc_<workload>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE).  bench.py cannot
     run the counter passes on itself, so this is null when no summary for the workload is committed."""
-    path = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
+    path = os.path.join(ROOT, "profiles", f"pmc_{workload}{'' if dtype == 'f32' else '_' + dtype}.json")
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
@@ -220,15 +244,51 @@ def pmc_traffic(workload, which, layout):
     return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
 
+def run_engine_mode(args, rank, world, dev):
+    """Engine-level throughput on the reference's profiling workload (tests/paged_for_profile.cpp:11-23):
+    B=1024 slots, S=128, D=2048, V=1024, 4096 pages, 2048 items with prompt length U[1,64], one forward round.
+    tokens/s = ThroughputCounter (tokens appended / wall time, host scheduling and copies included) -- the
+    figure README.md:54-82 quotes (123 284 tok/s on an unnamed NVIDIA GPU).  Each rank runs an independent
+    replica of the workload on its own GPU."""
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 1024, 128, 2048, 1024
+    rng = np.random.default_rng(0x5EED0100 + rank)
+
+    def u(*shape, scale=1.0):
+        return ((rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(scale)).astype(np.float32)
+
+    emb = u(V, D)
+    emb[ops.EOF_TOKEN_ID] *= 1.0001  # the reference scales the EOF row the same way
+    kind = {"paged": eng.PAGED, "paged_gemm": eng.PAGED_GEMM}[args.engine_kind]
+    e = eng.Engine(kind, B, S, D, V, emb, u(S, D), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)),
+                   u(D, D, scale=1 / np.sqrt(D)), n_blocks=4 * B, n_forward_rounds=1, device=dev.index,
+                   reference_length_reset_quirk=args.reference_quirk)
+    for i in range(2 * B):
+        e.add_item(i, rng.integers(0, ops.EOF_TOKEN_ID, size=int(rng.integers(1, 65))))
+    st = e.run()
+    assert st.finished == 2 * B
+    return st
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16"], default="auto",
+                    help="KV page / weight element type (accumulation, q, scores and outputs are always fp32); "
+                         "auto = what BASELINE.json names for the workload: bf16 for c4, fp32 for c2/c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", choices=["step", "engine"], default="step",
+                    help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
+    ap.add_argument("--engine-kind", choices=["paged", "paged_gemm"], default="paged_gemm")
+    ap.add_argument("--reference-quirk", action="store_true",
+                    help="engine mode: reproduce the reference's stale-length upload (DESIGN.md deviation 2)")
     args = ap.parse_args()
+    if args.dtype == "auto":
+        args.dtype = "bf16" if args.workload == "c4" else "f32"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,8 +302,35 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
 
+    if args.mode == "engine":
+        if world > 1:
+            dist.barrier()
+        st = run_engine_mode(args, rank, world, dev)
+        tok = torch.tensor([float(st.total_tokens)], device=dev)
+        sec = torch.tensor([st.seconds], device=dev)
+        if world > 1:
+            dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+            dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "decode tokens/sec (whole node) on synthetic batch", "value": tok.item() / sec.item(),
+                "unit": "tokens/s", "n_gpus": world, "steps": int(st.iterations), "warmup": 0,
+                "ms_per_step": sec.item() / max(int(st.iterations), 1) * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": tok.item() / sec.item() / world / 123284.0, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "engine: reference tests/paged_for_profile.cpp workload (B=1024 slots, S=128, "
+                                       "D=2048, V=1024, 4096 pages, 2048 items, prompt U[1,64]), "
+                                       f"{args.engine_kind} engine, ThroughputCounter tokens/s incl. host scheduling",
+                           "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
+                           "reference_length_reset_quirk": bool(args.reference_quirk),
+                           "total_tokens": tok.item(), "seconds": sec.item()}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     cfg_index = sorted(WORKLOADS).index(args.workload) + 1
-    wl = Workload(args.workload, dev, 0x5EED0000 + cfg_index * 16 + rank, headroom=args.steps + args.warmup + 8)
+    wl = Workload(args.workload, dev, 0x5EED0000 + cfg_index * 16 + rank, headroom=args.steps + args.warmup + 8,
+                  dtype=args.dtype)
     from min_llm_inference_amd.sharding import TokenGather
     gather = TokenGather(wl.B, world, dev)
 
@@ -286,11 +373,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
-                        f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[S/4,3S/4], fp32",
+                        f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[S/4,3S/4], "
+                        f"{'bf16 pages and weights, fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}",
             "rows_per_gpu": wl.B, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
             "mean_length": float(wl.lengths_host.mean()),
             "parallelism": f"row-sharded replicas x{world}, all-gather of token ids",
@@ -309,7 +397,7 @@ def main():
         dom = max(key_of, key=lambda k: times[key_of[k]])
         ms = times[key_of[dom]]
         achieved = alg[dom] / (ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload, dom, wl.layout)
+        traffic, traffic_src = pmc_traffic(args.workload, dom, wl.layout, args.dtype)
         out["roofline"] = {
             "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

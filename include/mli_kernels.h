@@ -132,6 +132,45 @@ int mli_paged_attention(float* const* page_table, const int* lengths,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bfloat16 paged path (BASELINE.json config 4).  EXTENSION: the reference is fp32 only, so these entry
+ * points have no reference counterpart; they are the fp32 paged entry points above with 16-bit pages
+ * (same layout rule, elements are bf16) and bf16 weights.  q_output, qkt_output, attention_result and
+ * every accumulation stay fp32.  Requires emb_dim % 8 == 0.  mli_bf16 = raw bfloat16 bits.
+ * ---------------------------------------------------------------------------------- */
+typedef uint16_t mli_bf16;
+
+int mli_fill_new_k_v_cache_paged_bf16(mli_bf16* const* page_table, const int* new_batch_idx, const int* lengths,
+                                      const mli_bf16* wk, const mli_bf16* wv,
+                                      int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream);
+
+int mli_get_latest_k_q_v_paged_bf16(mli_bf16* const* page_table, const int* lengths,
+                                    const mli_bf16* wk, const mli_bf16* wq, const mli_bf16* wv, float* q_output,
+                                    int n_batch, int n_sequence, int emb_dim, void* stream);
+
+int mli_qkt_paged_bf16(const float* q_output, const mli_bf16* const* page_table, const int* lengths,
+                       float* qkt_output, int n_batch, int n_sequence, int emb_dim, void* stream);
+
+int mli_softmax_v_paged_bf16(const float* softmax_result, const mli_bf16* const* page_table, const int* lengths,
+                             float* attention_result, int n_batch, int n_sequence, int emb_dim,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+int mli_paged_attention_bf16(mli_bf16* const* page_table, const int* lengths,
+                             const mli_bf16* wk, const mli_bf16* wq, const mli_bf16* wv, const int* new_batch_idx,
+                             float* q_output, float* qkt_output, float* attention_result,
+                             int n_batch, int n_sequence, int emb_dim, int n_new_items,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* fp32 embedding tables in, bf16 input embedding written into segment 0 of the page */
+int mli_paged_attention_encoder_bf16(const float* emb_table, const float* wpe, const int* inp,
+                                     mli_bf16* const* page_table, const int* lengths, const int* new_item_indices,
+                                     int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream);
+
+int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* emb_table, float* emb_score,
+                                        const float* wpe_table, mli_bf16* const* page_table, int* lengths,
+                                        int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                                        int n_decoder_results, int i_decoder, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Encoder / decoder head (needed for InferenceModel::forward).
  * ---------------------------------------------------------------------------------- */
 

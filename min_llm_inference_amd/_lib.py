@@ -53,6 +53,13 @@ SIGNATURES = {
     "mli_qkt_paged": [_P, _P, _P, _P, _I, _I, _I, _P],
     "mli_softmax_v_paged": [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
     "mli_paged_attention": [_P] * 9 + [_I] * 4 + [_P, _Z, _P],
+    "mli_fill_new_k_v_cache_paged_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mli_get_latest_k_q_v_paged_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mli_qkt_paged_bf16": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "mli_softmax_v_paged_bf16": [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
+    "mli_paged_attention_bf16": [_P] * 9 + [_I] * 4 + [_P, _Z, _P],
+    "mli_paged_attention_encoder_bf16": [_P] * 6 + [_I] * 4 + [_P],
+    "mli_paged_decoder_multi_rounds_bf16": [_P] * 7 + [_I] * 6 + [_P],
     "mli_inference_optimized_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_paged_attention_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_decoder": [_P] * 7 + [_I] * 4 + [_P],

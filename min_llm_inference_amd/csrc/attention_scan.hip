@@ -367,6 +367,16 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
 // ------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
+int chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence); }
+int nt_loads_enabled() { return g_nt_loads; }
+
+int launch_softmax_v_combine(const float* partial, const int* lengths, float* out, int B, int S, int D, int ct,
+                             int nchunk, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_v_combine_kernel, dim3(ceil_div_i(D, kScanThreads), B), dim3(kScanThreads), 0, st,
+                       partial, lengths, out, S, D, ct, nchunk);
+    return launch_status();
+}
+
 template <int VEC, bool PAGED>
 static int launch_softmax_v_impl(const float* probs, const void* src, const int* lengths, float* out,
                                  int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
@@ -399,9 +409,7 @@ static int launch_softmax_v_impl(const float* probs, const void* src, const int*
 #undef MLI_SV_LAUNCH
     int rc = launch_status();
     if (rc || direct) return rc;
-    hipLaunchKernelGGL(softmax_v_combine_kernel, dim3(ceil_div_i(D, kScanThreads), B), dim3(kScanThreads), 0, st,
-                       reinterpret_cast<const float*>(workspace), lengths, out, S, D, ct, nchunk);
-    return launch_status();
+    return launch_softmax_v_combine(reinterpret_cast<const float*>(workspace), lengths, out, B, S, D, ct, nchunk, st);
 }
 
 int launch_qkt_paged(const float* q, const float* const* page_table, const int* lengths, float* qkt,

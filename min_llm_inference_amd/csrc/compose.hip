@@ -19,11 +19,36 @@ int launch_softmax(float*, const int*, int, int, hipStream_t);
 int launch_softmax_v_naive(const float*, const float*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
 int launch_softmax_v_paged(const float*, const float* const*, const int*, float*, int, int, int, void*, size_t,
                            hipStream_t);
+int launch_latest_paged_bf16(uint16_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*, float*, int,
+                             int, int, hipStream_t);
+int launch_fill_paged_bf16(uint16_t* const*, const int*, const int*, const uint16_t*, const uint16_t*, int, int, int,
+                           int, hipStream_t);
+int launch_qkt_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, hipStream_t);
+int launch_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, void*, size_t,
+                                hipStream_t);
 }  // namespace mli
 
 extern "C" {
 
-int mli_abi_version(void) { return 1; }
+int mli_abi_version(void) { return 2; }
+
+int mli_paged_attention_bf16(mli_bf16* const* page_table, const int* lengths, const mli_bf16* wk, const mli_bf16* wq,
+                             const mli_bf16* wv, const int* new_batch_idx, float* q_output, float* qkt_output,
+                             float* attention_result, int n_batch, int n_sequence, int emb_dim, int n_new_items,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = mli::as_stream(stream);
+    int rc = mli::launch_fill_paged_bf16(page_table, new_batch_idx, lengths, wk, wv, n_batch, n_sequence, emb_dim,
+                                         n_new_items, st);
+    if (rc) return rc;
+    rc = mli::launch_latest_paged_bf16(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim, st);
+    if (rc) return rc;
+    rc = mli::launch_qkt_paged_bf16(q_output, page_table, lengths, qkt_output, n_batch, n_sequence, emb_dim, st);
+    if (rc) return rc;
+    rc = mli::launch_softmax(qkt_output, lengths, n_batch, n_sequence, st);
+    if (rc) return rc;
+    return mli::launch_softmax_v_paged_bf16(qkt_output, page_table, lengths, attention_result, n_batch, n_sequence,
+                                            emb_dim, workspace, workspace_bytes, st);
+}
 
 int mli_inference_self_attention(const float* inp_embedding, const int* lengths, const float* wk, const float* wq,
                                  const float* wv, const int* new_batch_idx, float* kt_cache, float* v_cache,

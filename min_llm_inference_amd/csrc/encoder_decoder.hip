@@ -13,8 +13,25 @@ int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int 
 
 constexpr int kEdThreads = 256;
 
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    auto cvt = [](float f) -> uint32_t {  // round to nearest even, NaN preserved
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return cvt(lo) | (cvt(hi) << 16);
+}
+
+// emb + wpe of 4 consecutive columns -> fp32 row or bf16 row
+template <bool BF16>
+__device__ __forceinline__ void store_sum4(float* dst_row, int i4, const float4& a, const float4& c) {
+    const float4 r = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    if (BF16) reinterpret_cast<uint2*>(dst_row)[i4] = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+    else reinterpret_cast<float4*>(dst_row)[i4] = r;
+}
+
 // One workgroup per (16-token group, new row); one wave per token, lanes along the embedding.
-template <bool PAGED>
+template <bool PAGED, bool BF16 = false>
 __global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
     const float* __restrict__ emb_table, const float* __restrict__ wpe, const int* __restrict__ inp,
     float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const int* __restrict__ lengths,
@@ -37,19 +54,16 @@ __global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
         const int tok = inp[(int64_t)b * S + s];
         const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
         const float4* p = reinterpret_cast<const float4*>(wpe + (int64_t)s * D);
-        float* dst = PAGED ? page_sh + page_row_offset(s, D, kSegInp)
-                           : inp_embedding + ((int64_t)b * S + s) * D;
-        float4* o = reinterpret_cast<float4*>(dst);
-        for (int i = lane; i < D4; i += kWave) {
-            const float4 a = e[i], c = p[i];
-            o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
-        }
+        float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + s) * D
+                     : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page_sh) + page_row_offset(s, D, kSegInp))
+                            : page_sh + page_row_offset(s, D, kSegInp);
+        for (int i = lane; i < D4; i += kWave) store_sum4<BF16>(dst, i, e[i], p[i]);
     }
 }
 
 // One workgroup per batch row.  argmax keeps the LOWEST index among equal maxima (the reference's
 // host decoder, tests/test_utils.cpp:607-614; its device kernel breaks ties by thread order).
-template <bool PAGED>
+template <bool PAGED, bool BF16 = false>
 __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     const float* __restrict__ emb_score, int* __restrict__ decoder_result, int* __restrict__ lengths,
     float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const float* __restrict__ wpe_table,
@@ -97,12 +111,10 @@ __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     if (L + 1 >= S || tok == MLI_EOF_TOKEN_ID || tok < 0) return;  // finished rows get no next embedding
     const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
     const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
-    float* dst = PAGED ? page_sh + page_row_offset(L, D, kSegInp) : inp_embedding + ((int64_t)b * S + L) * D;
-    float4* o = reinterpret_cast<float4*>(dst);
-    for (int i = threadIdx.x; i < (D >> 2); i += kEdThreads) {
-        const float4 a = e[i], c = p[i];
-        o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
-    }
+    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D
+                 : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page_sh) + page_row_offset(L, D, kSegInp))
+                        : page_sh + page_row_offset(L, D, kSegInp);
+    for (int i = threadIdx.x; i < (D >> 2); i += kEdThreads) store_sum4<BF16>(dst, i, e[i], p[i]);
 }
 
 // grid = (S/16, B).  Positions 0..min(L, S-1) inclusive are cloned (the decoder writes the next
@@ -152,6 +164,34 @@ int mli_paged_attention_encoder(const float* emb_table, const float* wpe, const 
     hipLaunchKernelGGL((mli::encoder_new_rows_kernel<true>), dim3(n_sequence / mli::kPage, n_new_items),
                        dim3(mli::kEdThreads), 0, mli::as_stream(stream), emb_table, wpe, inp, (float*)nullptr,
                        page_table, lengths, new_item_indices, n_sequence, emb_dim);
+    return mli::launch_status();
+}
+
+int mli_paged_attention_encoder_bf16(const float* emb_table, const float* wpe, const int* inp,
+                                     mli_bf16* const* page_table, const int* lengths, const int* new_item_indices,
+                                     int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream) {
+    if (n_new_items == 0) return 0;
+    if (n_new_items < 0 || emb_dim % 8 != 0 || n_sequence % mli::kPage != 0 || n_batch <= 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL((mli::encoder_new_rows_kernel<true, true>), dim3(n_sequence / mli::kPage, n_new_items),
+                       dim3(mli::kEdThreads), 0, mli::as_stream(stream), emb_table, wpe, inp, (float*)nullptr,
+                       reinterpret_cast<float* const*>(page_table), lengths, new_item_indices, n_sequence, emb_dim);
+    return mli::launch_status();
+}
+
+int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* emb_table, float* emb_score,
+                                        const float* wpe_table, mli_bf16* const* page_table, int* lengths,
+                                        int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                                        int n_decoder_results, int i_decoder, void* stream) {
+    if (emb_dim % 8 != 0 || n_sequence % mli::kPage != 0 || n_batch <= 0 || n_vocab <= 0 || n_decoder_results <= 0 ||
+        i_decoder < 0 || i_decoder >= n_decoder_results)
+        return MLI_ERR_BAD_ARG;
+    hipStream_t st = mli::as_stream(stream);
+    int rc = mli::launch_gemm_nt(batch_result, emb_table, emb_score, n_batch, n_vocab, emb_dim, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mli::decoder_argmax_kernel<true, true>), dim3(n_batch), dim3(mli::kEdThreads), 0, st,
+                       emb_score, decoder_result, lengths, (float*)nullptr,
+                       reinterpret_cast<float* const*>(page_table), wpe_table, emb_table, n_vocab, n_sequence,
+                       emb_dim, n_decoder_results, i_decoder);
     return mli::launch_status();
 }
 

@@ -57,10 +57,24 @@ struct GemmArgs {
 
 struct RowDesc {
     const float* a;  // nullptr -> row contributes zeros and is not stored
-    float* o;
+    float* o;        // BF16 kernels: both point at 16-bit elements and are reinterpreted at the access site
 };
 
-template <int MODE>
+// bf16 <-> fp32 (bf16 = the upper half of an fp32; products of two bf16 are exact in fp32)
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    // round to nearest even; NaN stays NaN (integer rounding alone would turn some NaNs into Inf/0)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive bf16 (8 bytes)
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
+template <int MODE, bool BF16>
 __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
     RowDesc r{nullptr, nullptr};
     if (MODE == kPlain) {
@@ -93,16 +107,26 @@ __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, 
         }
     } else {
         float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
-        float* tok = page + page_row_offset(s, g.K, kSegInp);
-        r.a = tok;
-        if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;
-        else r.o = tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;
+        if (BF16) {  // same layout rule, 16-bit elements
+            uint16_t* tok = reinterpret_cast<uint16_t*>(page) + page_row_offset(s, g.K, kSegInp);
+            r.a = reinterpret_cast<const float*>(tok);
+            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;  // q stays fp32
+            else r.o = reinterpret_cast<float*>(tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K);
+        } else {
+            float* tok = page + page_row_offset(s, g.K, kSegInp);
+            r.a = tok;
+            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;
+            else r.o = tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;
+        }
     }
     return r;
 }
 
 // VEC4: K % 4 == 0, N % 4 == 0 and 16-byte aligned rows -> float4 global loads.
-template <int MODE, bool BT, bool VEC4>
+// BF16 (paged modes only): x, W and the K/V outputs are bfloat16, q and the accumulation fp32.  Operands are
+// widened to fp32 while they are staged into LDS, so the product is still the exact fp32 MFMA chain
+// (bf16 x bf16 products are exact in fp32); a native v_mfma_f32_32x32x16_bf16 tile is the next step.
+template <int MODE, bool BT, bool VEC4, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ float As[BK * LDA];
     constexpr int LDBX = BT ? LDBT : LDB;
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
     const int tid = threadIdx.x;
     if (tid < BM) {
-        RowDesc r = resolve_row<MODE>(g, m0 + tid, z, out_id);
+        RowDesc r = resolve_row<MODE, BF16>(g, m0 + tid, z, out_id);
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
     }
@@ -155,7 +179,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
             const int k = k0 + a_kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ap != nullptr) {
-                if (VEC4) {
+                if (BF16) {
+                    if (k < g.K) v = load4_bf16(reinterpret_cast<const uint16_t*>(ap) + k);
+                } else if (VEC4) {
                     if (k < g.K) v = *reinterpret_cast<const float4*>(ap + k);
                 } else {
                     if (k + 0 < g.K) v.x = ap[k + 0];
@@ -188,7 +214,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
                 const int n = n0 + b_nq;
                 if (k < g.K) {
                     const float* bp = Bmat + (int64_t)k * g.N + n;
-                    if (VEC4) {
+                    if (BF16) {
+                        if (n < g.N) v = load4_bf16(reinterpret_cast<const uint16_t*>(Bmat) + (int64_t)k * g.N + n);
+                    } else if (VEC4) {
                         if (n < g.N) v = *reinterpret_cast<const float4*>(bp);
                     } else {
                         if (n + 0 < g.N) v.x = bp[0];
@@ -268,7 +296,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
             const int mi = wm + trow;
             const int n = n0 + wn + li;
             float* op = o_ptr[mi];
-            if (op != nullptr && n < g.N) op[n] = acc[r];
+            if (op != nullptr && n < g.N) {
+                if (BF16 && out_id != 1) reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[r]);
+                else op[n] = acc[r];
+            }
         }
     }
 }
@@ -338,6 +369,36 @@ int launch_fill_paged(float* const* page_table, const int* new_idx, const int* l
     return launch_gemm<kPagedFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
 }
 
+int launch_latest_paged_bf16(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,
+                             const uint16_t* wq, const uint16_t* wv, float* q, int B, int S, int D, hipStream_t st) {
+    if (B <= 0 || S % kPage != 0 || D % 8 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wq);
+    g.w[2] = reinterpret_cast<const float*>(wv); g.n_out = 3;
+    g.out_id[0] = 0; g.out_id[1] = 1; g.out_id[2] = 2;
+    g.M = B; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
+    g.B = B; g.S = S;
+    dim3 grid(ceil_div_i(D, BN) * 3, ceil_div_i(B, BM), 1);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<kPagedLatest, false, true, true>), grid, dim3(kGemmThreads), 0, st, g);
+    return launch_status();
+}
+
+int launch_fill_paged_bf16(uint16_t* const* page_table, const int* new_idx, const int* lengths, const uint16_t* wk,
+                           const uint16_t* wv, int B, int S, int D, int n_new, hipStream_t st) {
+    if (n_new == 0) return 0;
+    if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 8 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wv); g.n_out = 2;
+    g.out_id[0] = 0; g.out_id[1] = 2;
+    g.M = S; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.lengths = lengths; g.new_batch_idx = new_idx;
+    g.B = B; g.S = S;
+    dim3 grid(ceil_div_i(D, BN) * 2, ceil_div_i(S, BM), n_new);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<kPagedFill, false, true, true>), grid, dim3(kGemmThreads), 0, st, g);
+    return launch_status();
+}
+
 // C[M, N] = A[M, K] . Bt[N, K]^T
 int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int K, hipStream_t st) {
     if (M <= 0) return MLI_ERR_BAD_ARG;
@@ -379,6 +440,20 @@ int mli_get_latest_k_q_v_paged(float* const* page_table, const int* lengths, con
                                void* stream) {
     return mli::launch_latest_paged(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim,
                                     mli::as_stream(stream));
+}
+
+int mli_fill_new_k_v_cache_paged_bf16(mli_bf16* const* page_table, const int* new_batch_idx, const int* lengths,
+                                      const mli_bf16* wk, const mli_bf16* wv, int n_batch, int n_sequence,
+                                      int emb_dim, int n_new_items, void* stream) {
+    return mli::launch_fill_paged_bf16(page_table, new_batch_idx, lengths, wk, wv, n_batch, n_sequence, emb_dim,
+                                       n_new_items, mli::as_stream(stream));
+}
+
+int mli_get_latest_k_q_v_paged_bf16(mli_bf16* const* page_table, const int* lengths, const mli_bf16* wk,
+                                    const mli_bf16* wq, const mli_bf16* wv, float* q_output, int n_batch,
+                                    int n_sequence, int emb_dim, void* stream) {
+    return mli::launch_latest_paged_bf16(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim,
+                                         mli::as_stream(stream));
 }
 
 }  // extern "C"

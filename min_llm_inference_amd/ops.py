@@ -141,6 +141,66 @@ def paged_attention(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qk
 paged_attention_with_cublas = paged_attention  # one gather-GEMM-scatter kernel replaces the cuBLAS trio
 
 
+# ---- bf16 paged path (extension; BASELINE config 4).  page_table addresses point at bf16 pages ----------
+def launch_fill_new_k_v_cache_paged_attention_bf16(page_table, new_batch_idx, lengths, wk, wv, n_new_items, n_sequence):
+    B = page_table.shape[0]
+    _check(load_library().mli_fill_new_k_v_cache_paged_bf16(_p(page_table), _p(new_batch_idx), _p(lengths), _p(wk),
+                                                            _p(wv), B, n_sequence, wk.shape[0], n_new_items,
+                                                            _stream()), "mli_fill_new_k_v_cache_paged_bf16")
+
+
+def launch_get_latest_k_q_v_paged_attention_bf16(page_table, lengths, wk, wq, wv, q_output, n_sequence):
+    B = page_table.shape[0]
+    _check(load_library().mli_get_latest_k_q_v_paged_bf16(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv),
+                                                          _p(q_output), B, n_sequence, wq.shape[0], _stream()),
+           "mli_get_latest_k_q_v_paged_bf16")
+
+
+def launch_qkt_paged_attention_bf16(q_output, page_table, lengths, qkt_output):
+    B, D = q_output.shape
+    _check(load_library().mli_qkt_paged_bf16(_p(q_output), _p(page_table), _p(lengths), _p(qkt_output), B,
+                                             qkt_output.shape[1], D, _stream()), "mli_qkt_paged_bf16")
+
+
+def launch_softmax_v_paged_attention_bf16(softmax_result, page_table, attention_result, lengths):
+    B, S = softmax_result.shape
+    D = attention_result.shape[1]
+    ws, need = workspace_for(B, S, D, softmax_result.device)
+    _check(load_library().mli_softmax_v_paged_bf16(_p(softmax_result), _p(page_table), _p(lengths),
+                                                   _p(attention_result), B, S, D, _p(ws), need, _stream()),
+           "mli_softmax_v_paged_bf16")
+
+
+def paged_attention_bf16(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qkt_output, attention_result,
+                         n_new_items, n_sequence):
+    B = page_table.shape[0]
+    D = wk.shape[0]
+    ws, need = workspace_for(B, n_sequence, D, q_output.device)
+    _check(load_library().mli_paged_attention_bf16(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv),
+                                                   _p(new_batch_idx), _p(q_output), _p(qkt_output),
+                                                   _p(attention_result), B, n_sequence, D, n_new_items, _p(ws), need,
+                                                   _stream()), "mli_paged_attention_bf16")
+
+
+def launch_paged_attention_encoder_kernel_bf16(emb_table, wpe, inp, page_table, lengths, new_item_indices, n_new_items):
+    B, S = inp.shape
+    _check(load_library().mli_paged_attention_encoder_bf16(_p(emb_table), _p(wpe), _p(inp), _p(page_table),
+                                                           _p(lengths), _p(new_item_indices), B, S,
+                                                           emb_table.shape[1], n_new_items, _stream()),
+           "mli_paged_attention_encoder_bf16")
+
+
+def launch_paged_attention_decoder_multi_rounds_bf16(batch_result, emb_table, emb_score, wpe_table, page_table,
+                                                     lengths, decoder_result, i_decoder):
+    B, D = batch_result.shape
+    n_res = decoder_result.shape[1] if decoder_result.dim() == 2 else 1
+    _check(load_library().mli_paged_decoder_multi_rounds_bf16(_p(batch_result), _p(emb_table), _p(emb_score),
+                                                              _p(wpe_table), _p(page_table), _p(lengths),
+                                                              _p(decoder_result), B, emb_table.shape[0],
+                                                              wpe_table.shape[0], D, n_res, i_decoder, _stream()),
+           "mli_paged_decoder_multi_rounds_bf16")
+
+
 # ---- encoder / decoder ---------------------------------------------------------------------
 def launch_inference_optimized_encoder_kernel(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices,
                                               n_new_items):

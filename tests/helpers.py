@@ -139,3 +139,14 @@ def gather_rows_from_pool(pool, table, rows_bs, seg, emb_dim):
     s = np.asarray([r[1] for r in rows_bs])
     base = table[b, s // PAGE] + (s % PAGE) * 3 * emb_dim + seg * emb_dim
     return pool[(base[:, None] + np.arange(emb_dim)[None, :])]
+
+
+def bf16_bits(x):
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even (finite inputs)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_round(x):
+    """float32 values rounded to the nearest bfloat16, returned as float32."""
+    return (bf16_bits(x).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(x))

@@ -1,0 +1,101 @@
+"""GPU parity of the bf16 paged path (BASELINE config 4 dtype).  PARITY UNPINNED BY THE REFERENCE: it is fp32
+only.  Expectation = the fp32 CPU oracle evaluated on bf16-rounded inputs, with K/V rounded to bf16 where the
+kernels store them.  Products of two bf16 values are exact in fp32 and the MFMA accumulates in the oracle's k
+order, so q_output and the K/V written into the pages are compared BIT-EXACTLY; scores / probabilities /
+attention_result, whose sums run in a different order, within 1e-3 absolute (conditioned data, |values| ~ 1)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import host
+from helpers import assert_close, assert_equal, bf16_bits, bf16_round, paged_case
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(61, 37, 128, 64), (62, 24, 256, 512), (63, 6, 1024, 256), (64, 3, 4096, 512), (65, 5, 64, 2048), (66, 9, 96, 520)]
+
+
+def _case(oracle, dev, seed, B, S, D, zero_every=None):
+    c = paged_case(seed, B, S, D, conditioned=True, zero_every=zero_every)
+    for k in ("inp_embedding", "kt_cache", "v_cache", "wk", "wq", "wv", "pool"):
+        c[k] = bf16_round(c[k])
+    oracle.clone_to_pages(c["pool"], c["table"], c["inp_embedding"], c["kt_cache"], c["v_cache"], c["lengths"])
+    d = {k: torch.from_numpy(v.copy()).to(dev) for k, v in c.items()
+         if isinstance(v, np.ndarray) and k not in ("table", "pool", "wk", "wq", "wv")}
+    d["pool"] = torch.from_numpy(bf16_bits(c["pool"]).view(np.int16)).to(dev)  # raw bf16 bits
+    for w in ("wk", "wq", "wv"):
+        d[w] = torch.from_numpy(bf16_bits(c[w]).view(np.int16)).to(dev)
+    ptrs = np.where(c["table"] >= 0, d["pool"].data_ptr() + 2 * c["table"], 0).astype(np.int64)
+    d["page_table"] = torch.from_numpy(ptrs).to(dev)
+    return c, d
+
+
+@pytest.mark.parametrize("zero_every", [None, 4])
+@pytest.mark.parametrize("seed,B,S,D", SHAPES)
+def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every):
+    from min_llm_inference_amd import ops
+    c, d = _case(oracle, dev, seed, B, S, D, zero_every)
+    ops.paged_attention_bf16(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"],
+                             d["q_output"], d["qkt_output"], d["attention_result"], c["n_new"], S)
+    # oracle: fp32 on the bf16-rounded inputs; K/V are stored in bf16
+    oracle.fill_new_kt_v_cache(c["inp_embedding"], c["new_batch_idx"], c["lengths"], c["wk"], c["wv"], c["kt_cache"],
+                               c["v_cache"], c["n_new"])
+    oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
+                             c["q_output"])
+    c["kt_cache"] = bf16_round(c["kt_cache"])
+    c["v_cache"] = bf16_round(c["v_cache"])
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+
+    assert_equal(host(d["q_output"]), c["q_output"], what="q_output (bit exact)")
+    pool = host(d["pool"]).view(np.uint16)
+    new_rows = set(c["new_batch_idx"][:c["n_new"]].tolist())
+    for b in range(B):
+        L = int(c["lengths"][b])
+        for s in (range(L) if b in new_rows else ([L - 1] if L else [])):
+            off = c["table"][b, s // 16] + (s % 16) * 3 * D
+            assert_equal(pool[off + D:off + 2 * D], bf16_bits(c["kt_cache"][b, :, s]), what=f"K[{b},{s}] bits")
+            assert_equal(pool[off + 2 * D:off + 3 * D], bf16_bits(c["v_cache"][b, s]), what=f"V[{b},{s}] bits")
+    assert_close(host(d["qkt_output"]), c["qkt_output"], what="probabilities")
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+
+
+def test_bf16_encoder_decoder_write_bf16_embeddings(oracle, mli, dev):
+    """x = emb[tok] + wpe[s] is summed in fp32 and rounded once to bf16 in the page (encoder and decoder)."""
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(67)
+    B, S, D, V = 5, 64, 72, 1030
+    emb = (rng.random((V, D), dtype=np.float32) * 2 - 1).astype(np.float32)
+    wpe = (rng.random((S, D), dtype=np.float32) * 2 - 1).astype(np.float32)
+    lengths = np.array([0, 1, 16, 33, 62], np.int32)
+    inp = rng.integers(0, 1023, size=(B, S)).astype(np.int32)
+    npages = S // 16
+    pool = torch.zeros(B * npages * 16 * 3 * D, dtype=torch.int16, device=dev)
+    table = np.arange(B * npages, dtype=np.int64).reshape(B, npages) * (16 * 3 * D)
+    ptrs = torch.from_numpy(pool.data_ptr() + 2 * table).to(dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    new_idx = np.array([1, 2, 3, 4, 0], np.int32)
+    ops.launch_paged_attention_encoder_kernel_bf16(t(emb), t(wpe), t(inp), ptrs, t(lengths), t(new_idx), 4)
+    p = host(pool).view(np.uint16)
+    for b in range(B):
+        for s in range(int(lengths[b])):
+            off = table[b, s // 16] + (s % 16) * 3 * D
+            assert_equal(p[off:off + D], bf16_bits(emb[inp[b, s]] + wpe[s]), what=f"x[{b},{s}]")
+    assert (p.reshape(B, -1)[0] == 0).all()  # empty row untouched
+    # decoder: next embedding of each live row at position lengths[b]
+    att = (rng.random((B, D), dtype=np.float32) * 2 - 1).astype(np.float32)
+    d_len = t(lengths.copy())
+    res = torch.full((B, 1), 7, dtype=torch.int32, device=dev)
+    ops.launch_paged_attention_decoder_multi_rounds_bf16(t(att), t(emb), torch.zeros(B, V, device=dev), t(wpe), ptrs,
+                                                         d_len, res, 0)
+    toks = host(res).ravel()
+    exp = (att.astype(np.float64) @ emb.astype(np.float64).T).argmax(1)
+    p = host(pool).view(np.uint16)
+    assert toks[0] == -1
+    for b in range(1, B):
+        assert toks[b] == exp[b]
+        L = int(lengths[b])
+        off = table[b, L // 16] + (L % 16) * 3 * D
+        assert_equal(p[off:off + D], bf16_bits(emb[toks[b]] + wpe[L]), what=f"next x[{b}]")
+    assert_equal(host(d_len), np.array([0, 2, 17, 34, 63], np.int32))
