@@ -213,7 +213,10 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "chunk_tokens"     0 = heuristic, else a power of two in [64, 1024]: tokens per workgroup of the
  *                      split-sequence kernels
  *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
- *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch */
+ *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch
+ *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened
+ *                      to fp32 + fp32 MFMA (bit-identical to a sequential fp32 sum; differs from 1 only by the
+ *                      rounding order of the fp32 accumulation) */
 int mli_tune(const char* key, int value);
 
 /* float4 device copy used by bench.py to measure the achievable HBM copy rate on the box. */

@@ -20,6 +20,8 @@ constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kMaxChunkTokens = 1024;
 constexpr int kMinChunkTokens = 64;
 
+void set_bf16_native_mfma(int v);  // proj_gemm.hip
+
 // Tuning knobs (mli_tune): 0 = use the built-in heuristic / default.
 static int g_chunk_tokens = 0;
 static int g_nt_loads = 1;
@@ -505,6 +507,8 @@ int mli_tune(const char* key, int value) {
         mli::g_chunk_tokens = value;
     } else if (k == "nt_loads") {
         mli::g_nt_loads = value != 0;
+    } else if (k == "bf16_native_mfma") {
+        mli::set_bf16_native_mfma(value);
     } else if (k == "qkt_token_batch") {
         if (value != 4 && value != 8 && value != 16) return MLI_ERR_BAD_ARG;
         mli::g_qkt_token_batch = value;

@@ -1,0 +1,105 @@
+// Shared by the fp32 (proj_gemm.hip) and bf16 (proj_gemm_bf16.hip) MFMA GEMM kernels: the argument block and
+// the per-row source / destination resolution (page-table lookups happen here, once per workgroup).
+#pragma once
+
+#include "device_common.hpp"
+
+namespace mli {
+
+enum GemmMode : int {
+    kNaiveLatest = 0,
+    kNaiveFill = 1,
+    kPagedLatest = 2,
+    kPagedFill = 3,
+    kPlain = 4,  // C[M,N] = A[M,K] . B  (B is [K,N], or [N,K] when b_transposed)
+};
+
+struct GemmArgs {
+    // weights / B operands: up to three [K, N] matrices (k, q, v) -- or one [N, K] matrix (plain, transposed)
+    const float* w[3];
+    int n_out;       // how many of w[] are live
+    int out_id[3];   // which output each live weight feeds: 0 = K, 1 = Q, 2 = V
+    int M, N, K;     // M = rows per z-slice upper bound, N = out dim, K = in dim
+    // row sources / sinks
+    const float* a_plain;  // kPlain: A
+    float* c_plain;        // kPlain: C
+    int lda, ldc;
+    const float* inp_embedding;  // naive: [B, S, K]
+    float* kt_cache;             // naive: [B, N, S]
+    float* v_cache;              // naive: [B, S, N]
+    float* const* page_table;    // paged: [B, S/16]
+    float* q_output;             // latest: [B, N]
+    const int* lengths;
+    const int* new_batch_idx;    // fill
+    int B, S;
+};
+
+struct RowDesc {
+    const float* a;  // nullptr -> row contributes zeros and is not stored
+    float* o;        // BF16 kernels: both point at 16-bit elements and are reinterpreted at the access site
+};
+
+// bf16 <-> fp32 (bf16 = the upper half of an fp32; products of two bf16 are exact in fp32)
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    // round to nearest even; NaN stays NaN (integer rounding alone would turn some NaNs into Inf/0)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive bf16 (8 bytes)
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
+template <int MODE, bool BF16>
+__device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
+    RowDesc r{nullptr, nullptr};
+    if (MODE == kPlain) {
+        if (m < g.M) {
+            r.a = g.a_plain + (int64_t)m * g.lda;
+            r.o = g.c_plain + (int64_t)m * g.ldc;
+        }
+        return r;
+    }
+    int b, s;
+    if (MODE == kNaiveLatest || MODE == kPagedLatest) {
+        b = m;
+        if (b >= g.B) return r;
+        const int L = g.lengths[b];
+        if (L <= 0) return r;  // empty slot: nothing read, nothing written
+        s = L - 1;
+    } else {
+        b = g.new_batch_idx[z];
+        s = m;
+        if (s >= g.lengths[b]) return r;
+    }
+    if (MODE == kNaiveLatest || MODE == kNaiveFill) {
+        r.a = g.inp_embedding + ((int64_t)b * g.S + s) * g.K;
+        if (out_id == 0) {  // K is kept transposed: kt_cache[b, n, s]
+            r.o = g.kt_cache + (int64_t)b * g.N * g.S + s;
+        } else if (out_id == 1) {
+            r.o = g.q_output + (int64_t)b * g.N;
+        } else {
+            r.o = g.v_cache + ((int64_t)b * g.S + s) * g.N;
+        }
+    } else {
+        float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
+        if (BF16) {  // same layout rule, 16-bit elements
+            uint16_t* tok = reinterpret_cast<uint16_t*>(page) + page_row_offset(s, g.K, kSegInp);
+            r.a = reinterpret_cast<const float*>(tok);
+            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;  // q stays fp32
+            else r.o = reinterpret_cast<float*>(tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K);
+        } else {
+            float* tok = page + page_row_offset(s, g.K, kSegInp);
+            r.a = tok;
+            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;
+            else r.o = tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;
+        }
+    }
+    return r;
+}
+
+
+}  // namespace mli

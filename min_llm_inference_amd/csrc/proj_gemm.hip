@@ -15,7 +15,7 @@
 // (no TF32-style truncation).  Tile: 64x64x32 per 256-thread workgroup, 2x2 waves of 32x32.
 // Per-row source / destination pointers are resolved once per workgroup into LDS (this is where
 // the page table is read: one pointer per row, never inside the k loop).
-#include "device_common.hpp"
+#include "gemm_common.hpp"
 
 namespace mli {
 
@@ -26,101 +26,6 @@ constexpr int LDBT = BN + 1;  // [n][k] source (transposed B): same treatment as
 constexpr int kGemmThreads = 256;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-enum GemmMode : int {
-    kNaiveLatest = 0,
-    kNaiveFill = 1,
-    kPagedLatest = 2,
-    kPagedFill = 3,
-    kPlain = 4,  // C[M,N] = A[M,K] . B  (B is [K,N], or [N,K] when b_transposed)
-};
-
-struct GemmArgs {
-    // weights / B operands: up to three [K, N] matrices (k, q, v) -- or one [N, K] matrix (plain, transposed)
-    const float* w[3];
-    int n_out;       // how many of w[] are live
-    int out_id[3];   // which output each live weight feeds: 0 = K, 1 = Q, 2 = V
-    int M, N, K;     // M = rows per z-slice upper bound, N = out dim, K = in dim
-    // row sources / sinks
-    const float* a_plain;  // kPlain: A
-    float* c_plain;        // kPlain: C
-    int lda, ldc;
-    const float* inp_embedding;  // naive: [B, S, K]
-    float* kt_cache;             // naive: [B, N, S]
-    float* v_cache;              // naive: [B, S, N]
-    float* const* page_table;    // paged: [B, S/16]
-    float* q_output;             // latest: [B, N]
-    const int* lengths;
-    const int* new_batch_idx;    // fill
-    int B, S;
-};
-
-struct RowDesc {
-    const float* a;  // nullptr -> row contributes zeros and is not stored
-    float* o;        // BF16 kernels: both point at 16-bit elements and are reinterpreted at the access site
-};
-
-// bf16 <-> fp32 (bf16 = the upper half of an fp32; products of two bf16 are exact in fp32)
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    // round to nearest even; NaN stays NaN (integer rounding alone would turn some NaNs into Inf/0)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive bf16 (8 bytes)
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-}
-
-template <int MODE, bool BF16>
-__device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
-    RowDesc r{nullptr, nullptr};
-    if (MODE == kPlain) {
-        if (m < g.M) {
-            r.a = g.a_plain + (int64_t)m * g.lda;
-            r.o = g.c_plain + (int64_t)m * g.ldc;
-        }
-        return r;
-    }
-    int b, s;
-    if (MODE == kNaiveLatest || MODE == kPagedLatest) {
-        b = m;
-        if (b >= g.B) return r;
-        const int L = g.lengths[b];
-        if (L <= 0) return r;  // empty slot: nothing read, nothing written
-        s = L - 1;
-    } else {
-        b = g.new_batch_idx[z];
-        s = m;
-        if (s >= g.lengths[b]) return r;
-    }
-    if (MODE == kNaiveLatest || MODE == kNaiveFill) {
-        r.a = g.inp_embedding + ((int64_t)b * g.S + s) * g.K;
-        if (out_id == 0) {  // K is kept transposed: kt_cache[b, n, s]
-            r.o = g.kt_cache + (int64_t)b * g.N * g.S + s;
-        } else if (out_id == 1) {
-            r.o = g.q_output + (int64_t)b * g.N;
-        } else {
-            r.o = g.v_cache + ((int64_t)b * g.S + s) * g.N;
-        }
-    } else {
-        float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
-        if (BF16) {  // same layout rule, 16-bit elements
-            uint16_t* tok = reinterpret_cast<uint16_t*>(page) + page_row_offset(s, g.K, kSegInp);
-            r.a = reinterpret_cast<const float*>(tok);
-            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;  // q stays fp32
-            else r.o = reinterpret_cast<float*>(tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K);
-        } else {
-            float* tok = page + page_row_offset(s, g.K, kSegInp);
-            r.a = tok;
-            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;
-            else r.o = tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;
-        }
-    }
-    return r;
-}
 
 // VEC4: K % 4 == 0, N % 4 == 0 and 16-byte aligned rows -> float4 global loads.
 // BF16 (paged modes only): x, W and the K/V outputs are bfloat16, q and the accumulation fp32.  Operands are
@@ -369,9 +274,19 @@ int launch_fill_paged(float* const* page_table, const int* new_idx, const int* l
     return launch_gemm<kPagedFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
 }
 
+// bf16 tile engine: 1 = native v_mfma_f32_32x32x16_bf16 (proj_gemm_bf16.hip, default), 0 = operands widened to
+// fp32 in LDS + fp32 MFMA (bit-identical to a sequential fp32 sum; kept for parity checks).  mli_tune knob.
+static int g_bf16_native_mfma = 1;
+void set_bf16_native_mfma(int v) { g_bf16_native_mfma = v != 0; }
+int launch_latest_paged_bf16_native(uint16_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*,
+                                    float*, int, int, int, hipStream_t);
+int launch_fill_paged_bf16_native(uint16_t* const*, const int*, const int*, const uint16_t*, const uint16_t*, int, int,
+                                  int, int, hipStream_t);
+
 int launch_latest_paged_bf16(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,
                              const uint16_t* wq, const uint16_t* wv, float* q, int B, int S, int D, hipStream_t st) {
     if (B <= 0 || S % kPage != 0 || D % 8 != 0) return MLI_ERR_BAD_ARG;
+    if (g_bf16_native_mfma) return launch_latest_paged_bf16_native(page_table, lengths, wk, wq, wv, q, B, S, D, st);
     GemmArgs g{};
     g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wq);
     g.w[2] = reinterpret_cast<const float*>(wv); g.n_out = 3;
@@ -388,6 +303,7 @@ int launch_fill_paged_bf16(uint16_t* const* page_table, const int* new_idx, cons
                            const uint16_t* wv, int B, int S, int D, int n_new, hipStream_t st) {
     if (n_new == 0) return 0;
     if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 8 != 0) return MLI_ERR_BAD_ARG;
+    if (g_bf16_native_mfma) return launch_fill_paged_bf16_native(page_table, new_idx, lengths, wk, wv, B, S, D, n_new, st);
     GemmArgs g{};
     g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wv); g.n_out = 2;
     g.out_id[0] = 0; g.out_id[1] = 2;

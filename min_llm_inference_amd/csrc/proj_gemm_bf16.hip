@@ -1,0 +1,156 @@
+// bf16 MFMA GEMM for the bf16 paged path (BASELINE config 4): x[rows, D] . [Wk | Wq | Wv], bf16 operands,
+// fp32 accumulation (v_mfma_f32_32x32x16_bf16), K/V written back to the pages as bf16, q as fp32.
+// Same row gather / scatter front and back ends as the fp32 kernel (gemm_common.hpp); this file only differs in
+// the tile engine:
+//   * A (activations, k contiguous): staged row-major in LDS, fragments by ds_read_b128 (80-byte row stride:
+//     conflict-free);
+//   * B (weights, stored [k][n] with n contiguous, as the reference keeps them): staged row-major as loaded --
+//     no transposing stores -- and read with ds_read_b64_tr_b16, the gfx950 transposing LDS read, which hands
+//     each lane 4 consecutive k of its column (192-byte row stride: the 4 rows of a block land on disjoint
+//     quarters of the 64 banks);
+//   * 64x64x32 tile, 2x2 waves of 32x32, register-staged prefetch of the next tile under the MFMAs.
+#include "gemm_common.hpp"
+
+namespace mli {
+
+constexpr int HM = 64, HN = 64, HK = 32;
+constexpr int kLdaBytes = HK * 2 + 16;   // 80
+constexpr int kLdbBytes = HN * 2 + 64;   // 192
+constexpr int kHThreads = 256;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+union Frag8 {
+    bf16x8_t v;
+    uint4 u;
+    s16x4_t h[2];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
+    __shared__ __align__(16) unsigned char As[HM * kLdaBytes];
+    __shared__ __align__(16) unsigned char Bs[HK * kLdbBytes];
+    __shared__ const float* a_ptr[HM];
+    __shared__ float* o_ptr[HM];
+
+    const int tiles_n = (g.N + HN - 1) / HN;
+    const int wsel = blockIdx.x / tiles_n;
+    const int n0 = (blockIdx.x % tiles_n) * HN;
+    const int m0 = blockIdx.y * HM;
+    const int z = blockIdx.z;
+    const int out_id = g.out_id[wsel];
+    const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.w[wsel]);
+
+    if (MODE == kPagedFill) {
+        if (m0 >= g.lengths[g.new_batch_idx[z]]) return;  // workgroup-uniform: every lane leaves together
+    }
+    const int tid = threadIdx.x;
+    if (tid < HM) {
+        RowDesc r = resolve_row<MODE, true>(g, m0 + tid, z, out_id);
+        a_ptr[tid] = r.a;
+        o_ptr[tid] = r.o;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave >> 1) * 32;
+    const int wn = (wave & 1) * 32;
+
+    // staging coordinates: one 16-byte load per thread per operand per tile
+    const int a_row = tid >> 2, a_k8 = (tid & 3) * 8;   // A: 64 rows x 4 chunks of 8 k
+    const int b_row = tid >> 3, b_n8 = (tid & 7) * 8;   // B: 32 k-rows x 8 chunks of 8 n
+    uint4 a_reg, b_reg;
+
+    auto load_tile = [&](int k0) {
+        a_reg = make_uint4(0, 0, 0, 0);
+        b_reg = make_uint4(0, 0, 0, 0);
+        const uint16_t* ap = reinterpret_cast<const uint16_t*>(a_ptr[a_row]);
+        if (ap != nullptr && k0 + a_k8 < g.K) a_reg = *reinterpret_cast<const uint4*>(ap + k0 + a_k8);
+        const int k = k0 + b_row, n = n0 + b_n8;
+        if (k < g.K && n < g.N) b_reg = *reinterpret_cast<const uint4*>(W + (int64_t)k * g.N + n);
+    };
+    auto store_tile = [&]() {
+        *reinterpret_cast<uint4*>(&As[a_row * kLdaBytes + a_k8 * 2]) = a_reg;
+        *reinterpret_cast<uint4*>(&Bs[b_row * kLdbBytes + b_n8 * 2]) = b_reg;
+    };
+
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    // fragment addresses (constant over the k loop)
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned a_off = (unsigned)((wm + li) * kLdaBytes + lh * 16);
+    // transposing read: lane 4q+p of a 16-lane group points at row q, columns 4p..4p+3 of the group's 4x16 block
+    const int grp_col = wn + 16 * ((lane >> 4) & 1);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    const unsigned b_off = (unsigned)((8 * lh + tq) * kLdbBytes + (grp_col + 4 * tp) * 2);
+
+    const int nk = (g.K + HK - 1) / HK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load_tile((t + 1) * HK);
+#pragma unroll
+        for (int kk = 0; kk < HK; kk += 16) {
+            Frag8 a, b;
+            a.u = *reinterpret_cast<const uint4*>(&As[a_off + kk * 2]);
+            b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[b_off + kk * kLdbBytes]));
+            b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[b_off + (kk + 4) * kLdbBytes]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mi = wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = n0 + wn + li;
+        float* op = o_ptr[mi];
+        if (op != nullptr && n < g.N) {
+            if (out_id == 1) op[n] = acc[r];                                         // q: fp32
+            else reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[r]);            // K / V: bf16 page rows
+        }
+    }
+}
+
+int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,
+                                    const uint16_t* wq, const uint16_t* wv, float* q, int B, int S, int D,
+                                    hipStream_t st) {
+    GemmArgs g{};
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wq);
+    g.w[2] = reinterpret_cast<const float*>(wv); g.n_out = 3;
+    g.out_id[0] = 0; g.out_id[1] = 1; g.out_id[2] = 2;
+    g.M = B; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
+    g.B = B; g.S = S;
+    dim3 grid(ceil_div_i(D, HN) * 3, ceil_div_i(B, HM), 1);
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest>), grid, dim3(kHThreads), 0, st, g);
+    return launch_status();
+}
+
+int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_idx, const int* lengths,
+                                  const uint16_t* wk, const uint16_t* wv, int B, int S, int D, int n_new,
+                                  hipStream_t st) {
+    GemmArgs g{};
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wv); g.n_out = 2;
+    g.out_id[0] = 0; g.out_id[1] = 2;
+    g.M = S; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.lengths = lengths; g.new_batch_idx = new_idx;
+    g.B = B; g.S = S;
+    dim3 grid(ceil_div_i(D, HN) * 2, ceil_div_i(S, HM), n_new);
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedFill>), grid, dim3(kHThreads), 0, st, g);
+    return launch_status();
+}
+
+}  // namespace mli

@@ -30,10 +30,23 @@ def _case(oracle, dev, seed, B, S, D, zero_every=None):
     return c, d
 
 
+def _bits_within_one_ulp(got, want):
+    """bf16 values equal up to one bf16 ulp (2^-7 relative) plus the fp32 reassociation error of a 2048-term sum
+    (matters only where cancellation leaves a result near zero)."""
+    g = (got.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    w = (want.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    return (np.abs(g - w) <= 2.0 ** -7 * np.abs(w) + 1e-5).all()
+
+
+@pytest.mark.parametrize("native", [1, 0])
 @pytest.mark.parametrize("zero_every", [None, 4])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
-def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every):
+def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every, native):
+    """native=1: v_mfma_f32_32x32x16_bf16 (the hardware sums the 16 products of a step in its own order, so q and
+    the stored K/V may differ from the sequential fp32 oracle by fp32 rounding: q within 1e-4, K/V bits within one
+    bf16 ulp).  native=0: fp32-widened operands, bit-exact."""
     from min_llm_inference_amd import ops
+    assert mli.mli_tune(b"bf16_native_mfma", native) == 0
     c, d = _case(oracle, dev, seed, B, S, D, zero_every)
     ops.paged_attention_bf16(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"],
                              d["q_output"], d["qkt_output"], d["attention_result"], c["n_new"], S)
@@ -48,17 +61,27 @@ def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every):
     oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
     oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
 
-    assert_equal(host(d["q_output"]), c["q_output"], what="q_output (bit exact)")
+    mli.mli_tune(b"bf16_native_mfma", 1)
+    if native:
+        assert_close(host(d["q_output"]), c["q_output"], thr=1e-4, what="q_output")
+    else:
+        assert_equal(host(d["q_output"]), c["q_output"], what="q_output (bit exact)")
     pool = host(d["pool"]).view(np.uint16)
     new_rows = set(c["new_batch_idx"][:c["n_new"]].tolist())
     for b in range(B):
         L = int(c["lengths"][b])
         for s in (range(L) if b in new_rows else ([L - 1] if L else [])):
             off = c["table"][b, s // 16] + (s % 16) * 3 * D
-            assert_equal(pool[off + D:off + 2 * D], bf16_bits(c["kt_cache"][b, :, s]), what=f"K[{b},{s}] bits")
-            assert_equal(pool[off + 2 * D:off + 3 * D], bf16_bits(c["v_cache"][b, s]), what=f"V[{b},{s}] bits")
-    assert_close(host(d["qkt_output"]), c["qkt_output"], what="probabilities")
-    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+            if native:
+                assert _bits_within_one_ulp(pool[off + D:off + 2 * D], bf16_bits(c["kt_cache"][b, :, s])), f"K[{b},{s}]"
+                assert _bits_within_one_ulp(pool[off + 2 * D:off + 3 * D], bf16_bits(c["v_cache"][b, s])), f"V[{b},{s}]"
+            else:
+                assert_equal(pool[off + D:off + 2 * D], bf16_bits(c["kt_cache"][b, :, s]), what=f"K[{b},{s}] bits")
+                assert_equal(pool[off + 2 * D:off + 3 * D], bf16_bits(c["v_cache"][b, s]), what=f"V[{b},{s}] bits")
+    # a K/V element one bf16 ulp off moves a score by <= 2^-8 * |q_d * k_d| ~ 1e-3 at these magnitudes
+    tol = 5e-3 if native else 1e-3
+    assert_close(host(d["qkt_output"]), c["qkt_output"], thr=tol, what="probabilities")
+    assert_close(host(d["attention_result"]), c["attention_result"], thr=tol, what="attention_result")
 
 
 def test_bf16_encoder_decoder_write_bf16_embeddings(oracle, mli, dev):
