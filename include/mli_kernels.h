@@ -42,8 +42,9 @@ extern "C" {
 /* ABI version; bumped whenever a signature below changes. */
 int mli_abi_version(void);
 
-/* Bytes of device scratch the split-sequence kernels need for a problem of this size.
- * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention). */
+/* Bytes of device scratch the split-sequence kernels need for a problem of this size
+ * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention): per-chunk softmax statistics
+ * followed by the split-sequence partial sums.  Never 0 for a valid shape. */
 size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim);
 
 /* ------------------------------------------------------------------------------------
@@ -78,7 +79,7 @@ int mli_softmax_in_place_with_lengths(float* qkt_output, const int* lengths,
                                       int n_batch, int n_sequence, void* stream);
 
 /* replaces launch_softmax_v  (…optimized.h:24-26, …optimized.cu:370-383).
- * workspace may be NULL when mli_attention_workspace_bytes() returns 0. */
+ * workspace may be NULL only when n_sequence <= 64 (single chunk: nothing is staged). */
 int mli_softmax_v(const float* softmax_result, const float* v_cache, const int* lengths,
                   float* attention_result, int n_batch, int n_sequence, int output_dim,
                   void* workspace, size_t workspace_bytes, void* stream);
@@ -214,6 +215,9 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      split-sequence kernels
  *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
  *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch
+ *   "fused_softmax"    1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
+ *                      launches as the reference (qkt, softmax_in_place_with_lengths, softmax_v), -1 (default) =
+ *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
  *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened
  *                      to fp32 + fp32 MFMA (bit-identical to a sequential fp32 sum; differs from 1 only by the
  *                      rounding order of the fp32 accumulation) */

@@ -45,13 +45,22 @@ static int pick_chunk_tokens(int n_batch, int n_sequence) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Softmax fused into the two scan kernels (compositions only; the standalone launchers keep the reference's
+// three-kernel contract).  The qkt kernels additionally emit, per (row, chunk), the chunk's running maximum and
+// sum of exp(score - max); the softmax.V kernels turn the raw scores into probabilities on the fly
+// (p = exp(s - m_row) / l_row, with (m_row, l_row) merged from the row's chunk statistics), write them back to
+// qkt_output -- including the zero tail the reference's softmax kernel writes -- and accumulate p.V.  This
+// removes the softmax launch and one read + write pass over the scores.
+// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
 // qkt, paged layout.  grid = (B, ceil(S / ct)), block = 256.  Each wave takes whole pages.
 // ------------------------------------------------------------------------------------------
 template <int TB, bool NT>
 __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
     const float* __restrict__ q, const float* const* __restrict__ page_table,
-    const int* __restrict__ lengths, float* __restrict__ qkt, int S, int D, int ct) {
+    const int* __restrict__ lengths, float* __restrict__ qkt, int S, int D, int ct, SoftmaxStats st) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ float2 wave_stats[kScanWaves];
     // grid = (B, chunks): the row index is the fast dimension, so consecutive workgroups (which the
     // dispatcher deals round-robin to the 8 XCDs) are different rows of the SAME chunk -- every XCD
     // gets an equal share of each chunk, and the empty high chunks are dispatched last.
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
     const float scale = sqrtf((float)D);  // the reference divides by sqrtf(dim), so do we
     const int nj = (D4 + kWave - 1) / kWave;
 
+    float run_m = -INFINITY, run_l = 0.f;
     for (int pi = wave; pi < npages; pi += kScanWaves) {
         const float* page = wave_uniform(ptr_sh[pi]);
         const float* krow = page + D;  // segment 1 of token slot 0
@@ -105,7 +115,22 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
         }
         const float tot = wave_reduce16(acc, lane);
         const int s = s0 + pi * kPage + (lane >> 2);
-        if ((lane & 3) == 0 && s < L) qkt[(int64_t)b * S + s] = tot / scale;
+        const bool writer = (lane & 3) == 0 && s < L;
+        const float score = tot / scale;
+        if (writer) qkt[(int64_t)b * S + s] = score;
+        if (st.stats != nullptr) stats_accumulate(score, writer, run_m, run_l);
+    }
+    if (st.stats != nullptr) {  // merge the four waves, in wave order
+        if (lane == 0) wave_stats[wave] = make_float2(run_m, run_l);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = -INFINITY;
+            for (int w = 0; w < kScanWaves; ++w) m = fmaxf(m, wave_stats[w].x);
+            float l = 0.f;
+            for (int w = 0; w < kScanWaves; ++w)
+                if (wave_stats[w].x != -INFINITY) l += wave_stats[w].y * expf(wave_stats[w].x - m);
+            st.stats[(int64_t)b * st.per_row + blockIdx.y] = make_float2(m, l);
+        }
     }
 }
 
@@ -116,7 +141,7 @@ __global__ __launch_bounds__(kScanThreads) void qkt_paged_kernel(
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
     const float* __restrict__ q, const float* __restrict__ kt, const int* __restrict__ lengths,
-    float* __restrict__ qkt, int S, int D) {
+    float* __restrict__ qkt, int S, int D, SoftmaxStats st) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4 (*red)[kWave] = reinterpret_cast<float4 (*)[kWave]>(smem_raw);                // [waves][64] float4
     float* q_sh = reinterpret_cast<float*>(smem_raw + sizeof(float4) * kScanWaves * kWave);  // D floats
@@ -149,19 +174,28 @@ __global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && in_row) {
-        float4 r = red[0][lane];
+    if (wave == 0) {  // whole wave stays in (the statistics below are wave-wide reductions)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (in_row) {
+            float4 r = red[0][lane];
 #pragma unroll
-        for (int w = 1; w < kScanWaves; ++w) {
-            r.x += red[w][lane].x; r.y += red[w][lane].y; r.z += red[w][lane].z; r.w += red[w][lane].w;
+            for (int w = 1; w < kScanWaves; ++w) {
+                r.x += red[w][lane].x; r.y += red[w][lane].y; r.z += red[w][lane].z; r.w += red[w][lane].w;
+            }
+            const float scale = sqrtf((float)D);
+            float* out = qkt + (int64_t)b * S + s;
+            v[0] = r.x / scale; v[1] = r.y / scale; v[2] = r.z / scale; v[3] = r.w / scale;
+            if (s + 4 <= L) {
+                *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int u = 0; u < 4; ++u) if (s + u < L) out[u] = v[u];   // never write past lengths[b]
+            }
         }
-        const float scale = sqrtf((float)D);
-        float* out = qkt + (int64_t)b * S + s;
-        const float v[4] = {r.x / scale, r.y / scale, r.z / scale, r.w / scale};
-        if (s + 4 <= L) {
-            *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            for (int u = 0; u < 4; ++u) if (s + u < L) out[u] = v[u];   // never write past lengths[b]
+        if (st.stats != nullptr) {
+            float m = -INFINITY, l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stats_accumulate(v[u], in_row && s + u < L, m, l);
+            if (lane == 0) st.stats[(int64_t)b * st.per_row + blockIdx.y] = make_float2(m, l);
         }
     }
 }
@@ -243,8 +277,8 @@ template <> __device__ __forceinline__ float vload<1>(const float* p, bool nt) {
 
 template <int VEC, int NJ, bool PAGED, bool NT>
 __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
-    const float* __restrict__ probs, const void* __restrict__ src, const int* __restrict__ lengths,
-    float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct) {
+    float* __restrict__ probs, const void* __restrict__ src, const int* __restrict__ lengths,
+    float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct, SoftmaxStats st) {
     using V = typename VecT<VEC>::type;
     constexpr int kSliceV = kWave * NJ;          // V-elements per d-slice
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -257,22 +291,36 @@ __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
     const int L = min(lengths[b], S);
     const int s0 = c * ct;
     const int Dv = D / VEC;
-    const int v0 = blockIdx.z * kSliceV;         // first V-element of this slice
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
+    const bool fused = st.stats != nullptr;
+    float* prow = probs + (int64_t)b * S + s0;
+    const int span = min(ct, S - s0);            // positions of this chunk that exist in the row
 
     if (s0 >= L) {
+        // fused: this chunk lies in the zero tail the reference's softmax kernel writes
+        if (fused) for (int i = threadIdx.x; i < span; i += kScanThreads) prow[i] = 0.f;
         // an empty row still owes zeros to attention_result (reference softmax_v: result = 0)
         if (direct && c == 0) {
             V* o = reinterpret_cast<V*>(dst + (int64_t)b * D);
-            for (int i = threadIdx.x; i < kSliceV; i += kScanThreads)
-                if (v0 + i < Dv) o[v0 + i] = vzero<VEC>();
+            for (int i = threadIdx.x; i < Dv; i += kScanThreads) o[i] = vzero<VEC>();
         }
         return;
     }
     const int s1 = min(s0 + ct, L);
     const int ntok = s1 - s0;
-    for (int i = threadIdx.x; i < ntok; i += kScanThreads) p_sh[i] = probs[(int64_t)b * S + s0 + i];
+    if (fused) {
+        float m, l;
+        stats_merge_row(st, b, L, lane, m, l);
+        const float inv_l = 1.f / l;
+        for (int i = threadIdx.x; i < span; i += kScanThreads) {
+            const float p = i < ntok ? expf(prow[i] - m) * inv_l : 0.f;
+            prow[i] = p;               // probabilities (and the zero tail) replace the raw scores
+            if (i < ntok) p_sh[i] = p;
+        }
+    } else {
+        for (int i = threadIdx.x; i < ntok; i += kScanThreads) p_sh[i] = prow[i];
+    }
     if (PAGED) {
         const float* const* pt = reinterpret_cast<const float* const*>(src);
         const int npages = (ntok + kPage - 1) / kPage;
@@ -281,65 +329,70 @@ __global__ __launch_bounds__(kScanThreads) void softmax_v_partial_kernel(
     }
     __syncthreads();
 
-    V acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = vzero<VEC>();
-    bool live[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) live[j] = (v0 + lane + j * kWave) < Dv;
-
     const int ngroups = (ntok + kPage - 1) / kPage;  // 16-token groups (pages when PAGED)
     constexpr int TB = 4;                            // rows in flight per load batch (x NJ loads each)
-    const unsigned lane_bytes = (unsigned)(v0 + lane) * (unsigned)sizeof(V);
     const int64_t stride_f = PAGED ? 3 * (int64_t)D : (int64_t)D;  // floats between consecutive tokens
-    for (int g = wave; g < ngroups; g += kScanWaves) {
-        // wave-uniform base of the group's first V row (SGPRs); lanes add one 32-bit byte offset
-        const float* base = PAGED ? wave_uniform(ptr_sh[g]) + 2 * (int64_t)D
-                                  : reinterpret_cast<const float*>(src) + ((int64_t)b * S + s0 + g * kPage) * D;
-        const int nt = min(kPage, ntok - g * kPage);
-        const float* pg = p_sh + g * kPage;
-        if (nt == kPage) {
-#pragma unroll 1
-            for (int h = 0; h < kPage / TB; ++h) {
-                V vb[TB][NJ];
+    V* o = direct ? reinterpret_cast<V*>(dst + (int64_t)b * D)
+                  : reinterpret_cast<V*>(dst + ((int64_t)b * nchunk_max + c) * D);
+
+    // rows wider than one slice (64 * NJ lane loads) are swept slice by slice; p_sh is reused
+    for (int v0 = 0; v0 < Dv; v0 += kSliceV) {
+        V acc[NJ];
+        bool live[NJ];
 #pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    const float* trow = base + (int64_t)(h * TB + t) * stride_f;
+        for (int j = 0; j < NJ; ++j) {
+            acc[j] = vzero<VEC>();
+            live[j] = (v0 + lane + j * kWave) < Dv;
+        }
+        const unsigned lane_bytes = (unsigned)(v0 + lane) * (unsigned)sizeof(V);
+        for (int g = wave; g < ngroups; g += kScanWaves) {
+            // wave-uniform base of the group's first V row (SGPRs); lanes add one 32-bit byte offset
+            const float* base = PAGED ? wave_uniform(ptr_sh[g]) + 2 * (int64_t)D
+                                      : reinterpret_cast<const float*>(src) + ((int64_t)b * S + s0 + g * kPage) * D;
+            const int nt = min(kPage, ntok - g * kPage);
+            const float* pg = p_sh + g * kPage;
+            if (nt == kPage) {
+#pragma unroll 1
+                for (int h = 0; h < kPage / TB; ++h) {
+                    V vb[TB][NJ];
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        const float* trow = base + (int64_t)(h * TB + t) * stride_f;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            if (live[j])
+                                vb[t][j] = vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        const float p = pg[h * TB + t];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            if (live[j]) vfma<VEC>(p, vb[t][j], acc[j]);
+                    }
+                }
+            } else {
+                for (int t = 0; t < nt; ++t) {
+                    const float p = pg[t];
+                    const float* trow = base + (int64_t)t * stride_f;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         if (live[j])
-                            vb[t][j] = vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT);
+                            vfma<VEC>(p, vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT), acc[j]);
                 }
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    const float p = pg[h * TB + t];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        if (live[j]) vfma<VEC>(p, vb[t][j], acc[j]);
-                }
-            }
-        } else {
-            for (int t = 0; t < nt; ++t) {
-                const float p = pg[t];
-                const float* trow = base + (int64_t)t * stride_f;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (live[j])
-                        vfma<VEC>(p, vload<VEC>(reinterpret_cast<const V*>(byte_offset(trow, lane_bytes + j * kWave * (unsigned)sizeof(V))), NT), acc[j]);
             }
         }
-    }
+        if (v0 > 0) __syncthreads();  // the previous slice's sums have been consumed
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) red[wave * kSliceV + lane + j * kWave] = acc[j];
-    __syncthreads();
-    V* o = direct ? reinterpret_cast<V*>(dst + (int64_t)b * D)
-                  : reinterpret_cast<V*>(dst + ((int64_t)b * nchunk_max + c) * D);
-    for (int i = threadIdx.x; i < kSliceV; i += kScanThreads) {
-        if (v0 + i < Dv) {
-            V r = red[i];
+        for (int j = 0; j < NJ; ++j) red[wave * kSliceV + lane + j * kWave] = acc[j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < kSliceV; i += kScanThreads) {
+            if (v0 + i < Dv) {
+                V r = red[i];
 #pragma unroll
-            for (int w = 1; w < kScanWaves; ++w) vadd<VEC>(r, red[w * kSliceV + i]);
-            o[v0 + i] = r;
+                for (int w = 1; w < kScanWaves; ++w) vadd<VEC>(r, red[w * kSliceV + i]);
+                o[v0 + i] = r;
+            }
         }
     }
 }
@@ -379,49 +432,66 @@ int launch_softmax_v_combine(const float* partial, const int* lengths, float* ou
     return launch_status();
 }
 
+// Workspace layout (mli_attention_workspace_bytes): [chunk statistics: B * ceil(S/64) float2, 256-B aligned]
+// [softmax.V partial sums: B * nchunk * D floats].
+static size_t stats_region_bytes(int B, int S) {
+    const size_t n = (size_t)B * ceil_div_i(S, kMinChunkTokens) * sizeof(float2);
+    return (n + 255) & ~(size_t)255;
+}
+
+static SoftmaxStats stats_view(void* workspace, int B, int S, int chunk_tokens) {
+    SoftmaxStats st;
+    st.stats = reinterpret_cast<float2*>(workspace);
+    st.per_row = ceil_div_i(S, kMinChunkTokens);
+    st.chunk_tokens = chunk_tokens;
+    return st;
+}
+
 template <int VEC, bool PAGED>
-static int launch_softmax_v_impl(const float* probs, const void* src, const int* lengths, float* out,
-                                 int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
+static int launch_softmax_v_impl(float* probs, const void* src, const int* lengths, float* out,
+                                 int B, int S, int D, void* workspace, size_t ws_bytes, SoftmaxStats st_in,
+                                 hipStream_t st) {
     const int Dv = D / VEC;
-    const int nj = min(2, ceil_div_i(Dv, kWave));  // <= 64 VGPRs -> 8 waves/SIMD; wider rows become d-slices (grid.z)
+    const int nj = min(2, ceil_div_i(Dv, kWave));  // <= 64 VGPRs -> 8 waves/SIMD; wider rows are swept in slices
     const int slice_v = kWave * nj;
-    const int nslices = ceil_div_i(Dv, slice_v);
     int ct = pick_chunk_tokens(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     float* dst = out;
     if (!direct) {
-        const size_t need = (size_t)B * nchunk * D * sizeof(float);
+        const size_t need = stats_region_bytes(B, S) + (size_t)B * nchunk * D * sizeof(float);
         if (workspace == nullptr || ws_bytes < need) return MLI_ERR_WORKSPACE;
-        dst = reinterpret_cast<float*>(workspace);
+        dst = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + stats_region_bytes(B, S));
     }
     const size_t smem = (size_t)ct * 4 + (size_t)(ct / kPage) * 8 + (size_t)kScanWaves * slice_v * VEC * 4;
-    dim3 grid(B, nchunk, nslices);
+    dim3 grid(B, nchunk);
 #define MLI_SV_LAUNCH(NJ)                                                                                  \
     do {                                                                                                   \
         if (g_nt_loads)                                                                                    \
             hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED, true>), grid, dim3(kScanThreads), smem, st, \
-                               probs, src, lengths, dst, S, D, ct, nchunk, direct);                        \
+                               probs, src, lengths, dst, S, D, ct, nchunk, direct, st_in);                 \
         else                                                                                               \
             hipLaunchKernelGGL((softmax_v_partial_kernel<VEC, NJ, PAGED, false>), grid, dim3(kScanThreads), smem, st, \
-                               probs, src, lengths, dst, S, D, ct, nchunk, direct);                        \
+                               probs, src, lengths, dst, S, D, ct, nchunk, direct, st_in);                 \
     } while (0)
     if (nj == 1) MLI_SV_LAUNCH(1);
     else MLI_SV_LAUNCH(2);
 #undef MLI_SV_LAUNCH
     int rc = launch_status();
     if (rc || direct) return rc;
-    return launch_softmax_v_combine(reinterpret_cast<const float*>(workspace), lengths, out, B, S, D, ct, nchunk, st);
+    return launch_softmax_v_combine(dst, lengths, out, B, S, D, ct, nchunk, st);
 }
 
-int launch_qkt_paged(const float* q, const float* const* page_table, const int* lengths, float* qkt,
-                     int B, int S, int D, hipStream_t st) {
+static const SoftmaxStats kNoStats{nullptr, 0, 0};
+
+int launch_qkt_paged_stats(const float* q, const float* const* page_table, const int* lengths, float* qkt,
+                           int B, int S, int D, SoftmaxStats stats, hipStream_t st) {
     if (S % kPage != 0 || D % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
     const int ct = pick_chunk_tokens(B, S);
     const size_t smem = (size_t)D * 4 + (size_t)(ct / kPage) * 8;
     dim3 grid(B, ceil_div_i(S, ct));
 #define MLI_QKT_LAUNCH(TB, NT) \
-    hipLaunchKernelGGL((qkt_paged_kernel<TB, NT>), grid, dim3(kScanThreads), smem, st, q, page_table, lengths, qkt, S, D, ct)
+    hipLaunchKernelGGL((qkt_paged_kernel<TB, NT>), grid, dim3(kScanThreads), smem, st, q, page_table, lengths, qkt, S, D, ct, stats)
     if (g_qkt_token_batch == 16) { if (g_nt_loads) MLI_QKT_LAUNCH(16, true); else MLI_QKT_LAUNCH(16, false); }
     else if (g_qkt_token_batch == 4) { if (g_nt_loads) MLI_QKT_LAUNCH(4, true); else MLI_QKT_LAUNCH(4, false); }
     else { if (g_nt_loads) MLI_QKT_LAUNCH(8, true); else MLI_QKT_LAUNCH(8, false); }
@@ -429,12 +499,22 @@ int launch_qkt_paged(const float* q, const float* const* page_table, const int* 
     return launch_status();
 }
 
-int launch_qkt_naive(const float* q, const float* kt, const int* lengths, float* qkt, int B, int S, int D,
-                     hipStream_t st) {
+int launch_qkt_paged(const float* q, const float* const* page_table, const int* lengths, float* qkt,
+                     int B, int S, int D, hipStream_t st) {
+    return launch_qkt_paged_stats(q, page_table, lengths, qkt, B, S, D, kNoStats, st);
+}
+
+int launch_qkt_naive_stats(const float* q, const float* kt, const int* lengths, float* qkt, int B, int S, int D,
+                           SoftmaxStats stats, hipStream_t st) {
     if (S % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
     hipLaunchKernelGGL(qkt_naive_kernel, dim3(B, ceil_div_i(S, 256)), dim3(kScanThreads),
-                       sizeof(float4) * kScanWaves * kWave + (size_t)D * 4, st, q, kt, lengths, qkt, S, D);
+                       sizeof(float4) * kScanWaves * kWave + (size_t)D * 4, st, q, kt, lengths, qkt, S, D, stats);
     return launch_status();
+}
+
+int launch_qkt_naive(const float* q, const float* kt, const int* lengths, float* qkt, int B, int S, int D,
+                     hipStream_t st) {
+    return launch_qkt_naive_stats(q, kt, lengths, qkt, B, S, D, kNoStats, st);
 }
 
 int launch_softmax(float* qkt, const int* lengths, int B, int S, hipStream_t st) {
@@ -447,14 +527,65 @@ int launch_softmax(float* qkt, const int* lengths, int B, int S, hipStream_t st)
 int launch_softmax_v_naive(const float* probs, const float* v_cache, const int* lengths, float* out,
                            int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
     if (B <= 0 || S <= 0 || D <= 0) return MLI_ERR_BAD_ARG;
-    if (D % 4 == 0) return launch_softmax_v_impl<4, false>(probs, v_cache, lengths, out, B, S, D, ws, ws_bytes, st);
-    return launch_softmax_v_impl<1, false>(probs, v_cache, lengths, out, B, S, D, ws, ws_bytes, st);
+    float* p = const_cast<float*>(probs);  // only written in the fused mode
+    if (D % 4 == 0) return launch_softmax_v_impl<4, false>(p, v_cache, lengths, out, B, S, D, ws, ws_bytes, kNoStats, st);
+    return launch_softmax_v_impl<1, false>(p, v_cache, lengths, out, B, S, D, ws, ws_bytes, kNoStats, st);
 }
 
 int launch_softmax_v_paged(const float* probs, const float* const* page_table, const int* lengths, float* out,
                            int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
     if (S % kPage != 0 || D % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
-    return launch_softmax_v_impl<4, true>(probs, page_table, lengths, out, B, S, D, ws, ws_bytes, st);
+    return launch_softmax_v_impl<4, true>(const_cast<float*>(probs), page_table, lengths, out, B, S, D, ws, ws_bytes,
+                                          kNoStats, st);
+}
+
+// ---- fused compositions: scores + chunk statistics, then softmax folded into softmax.V ------------------
+// 1 = always fuse, 0 = never, -1 (default) = fuse when the step is launch-bound.  Measured on MI355X: folding the
+// softmax into softmax.V lengthens every workgroup's prologue (statistics -> exp -> write-back before the first V
+// load), which costs ~10 us at B*S = 4M (BASELINE config 4) but saves a launch and a pass over the scores, worth
+// 10-15 % of the step at B*S = 256K (configs 2/3).
+static int g_fused_softmax = -1;
+
+static bool can_fuse(int B, int S, int stats_chunk, void* ws, size_t ws_bytes) {
+    const bool want = g_fused_softmax == 1 || (g_fused_softmax < 0 && (int64_t)B * S <= (1 << 20));
+    // stats_merge_row() holds at most 256 chunk entries per row in registers
+    return want && ws != nullptr && ws_bytes >= stats_region_bytes(B, S) && ceil_div_i(S, stats_chunk) <= 256;
+}
+
+int launch_scores_softmax_v_paged(const float* q, const float* const* page_table, const int* lengths, float* qkt,
+                                  float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!can_fuse(B, S, pick_chunk_tokens(B, S), ws, ws_bytes)) {
+        int rc = launch_qkt_paged(q, page_table, lengths, qkt, B, S, D, st);
+        if (!rc) rc = launch_softmax(qkt, lengths, B, S, st);
+        if (!rc) rc = launch_softmax_v_paged(qkt, page_table, lengths, out, B, S, D, ws, ws_bytes, st);
+        return rc;
+    }
+    const SoftmaxStats stats = stats_view(ws, B, S, pick_chunk_tokens(B, S));
+    int rc = launch_qkt_paged_stats(q, page_table, lengths, qkt, B, S, D, stats, st);
+    if (rc) return rc;
+    return launch_softmax_v_impl<4, true>(qkt, page_table, lengths, out, B, S, D, ws, ws_bytes, stats, st);
+}
+
+int launch_scores_softmax_v_naive(const float* q, const float* kt, const float* v_cache, const int* lengths,
+                                  float* qkt, float* out, int B, int S, int D, void* ws, size_t ws_bytes,
+                                  hipStream_t st) {
+    if (!can_fuse(B, S, 256, ws, ws_bytes)) {
+        int rc = launch_qkt_naive(q, kt, lengths, qkt, B, S, D, st);
+        if (!rc) rc = launch_softmax(qkt, lengths, B, S, st);
+        if (!rc) rc = launch_softmax_v_naive(qkt, v_cache, lengths, out, B, S, D, ws, ws_bytes, st);
+        return rc;
+    }
+    const SoftmaxStats stats = stats_view(ws, B, S, 256);  // qkt_naive_kernel covers 256 tokens per workgroup
+    int rc = launch_qkt_naive_stats(q, kt, lengths, qkt, B, S, D, stats, st);
+    if (rc) return rc;
+    if (D % 4 == 0) return launch_softmax_v_impl<4, false>(qkt, v_cache, lengths, out, B, S, D, ws, ws_bytes, stats, st);
+    return launch_softmax_v_impl<1, false>(qkt, v_cache, lengths, out, B, S, D, ws, ws_bytes, stats, st);
+}
+
+// exported to attention_scan_bf16.hip
+size_t stats_region_bytes_for(int B, int S) { return stats_region_bytes(B, S); }
+int fused_softmax_wanted(int B, int S) {
+    return g_fused_softmax == 1 || (g_fused_softmax < 0 && (int64_t)B * S <= (1 << 20));
 }
 
 }  // namespace mli
@@ -463,10 +594,10 @@ extern "C" {
 
 size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim) {
     if (n_batch <= 0 || n_sequence <= 0 || dim <= 0) return 0;
-    // sized for the smallest chunk the heuristic (or MLI_CHUNK_TOKENS) may choose
+    // [chunk statistics][partial sums], sized for the smallest chunk the heuristic (or the tuning knob) may choose
     const size_t nchunk = (size_t)mli::ceil_div_i(n_sequence, mli::kMinChunkTokens);
-    if (nchunk <= 1) return 0;
-    return (size_t)n_batch * nchunk * (size_t)dim * sizeof(float);
+    const size_t partial = nchunk <= 1 ? 0 : (size_t)n_batch * nchunk * (size_t)dim * sizeof(float);
+    return mli::stats_region_bytes(n_batch, n_sequence) + partial;
 }
 
 int mli_qkt(const float* q_output, const float* kt_cache, const int* lengths, float* qkt_output,
@@ -507,6 +638,8 @@ int mli_tune(const char* key, int value) {
         mli::g_chunk_tokens = value;
     } else if (k == "nt_loads") {
         mli::g_nt_loads = value != 0;
+    } else if (k == "fused_softmax") {
+        mli::g_fused_softmax = value < 0 ? -1 : (value != 0);
     } else if (k == "bf16_native_mfma") {
         mli::set_bf16_native_mfma(value);
     } else if (k == "qkt_token_batch") {

@@ -10,8 +10,11 @@ namespace mli {
 constexpr int kBfThreads = 256;
 constexpr int kBfWaves = kBfThreads / kWave;
 
-int chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip (same heuristic / tuning knob)
+int chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip (same heuristic / tuning knobs)
 int nt_loads_enabled();
+int fused_softmax_wanted(int B, int S);
+size_t stats_region_bytes_for(int B, int S);
+int launch_softmax(float*, const int*, int, int, hipStream_t);
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef const u32x4_t __attribute__((address_space(1)))* gu4_ptr;
@@ -50,8 +53,9 @@ __device__ __forceinline__ float dot8(const float4& qa, const float4& qb, const 
 template <int TB, bool NT>
 __global__ __launch_bounds__(kBfThreads) void qkt_paged_bf16_kernel(
     const float* __restrict__ q, const uint16_t* const* __restrict__ page_table, const int* __restrict__ lengths,
-    float* __restrict__ qkt, int S, int D, int ct) {
+    float* __restrict__ qkt, int S, int D, int ct, SoftmaxStats st) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ float2 wave_stats[kBfWaves];
     const int b = blockIdx.x;
     const int L = lengths[b];
     const int s0 = blockIdx.y * ct;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(kBfThreads) void qkt_paged_bf16_kernel(
     const int nj = (D8 + kWave - 1) / kWave;
     const int64_t row_bytes = (int64_t)3 * D * 2;  // bytes between consecutive token slots
 
+    float run_m = -INFINITY, run_l = 0.f;
     for (int pi = wave; pi < npages; pi += kBfWaves) {
         const uint16_t* krow = wave_uniform16(ptr_sh[pi]) + D;  // segment 1 of slot 0
         float acc[16];
@@ -96,15 +101,30 @@ __global__ __launch_bounds__(kBfThreads) void qkt_paged_bf16_kernel(
         }
         const float tot = wave_reduce16(acc, lane);
         const int s = s0 + pi * kPage + (lane >> 2);
-        if ((lane & 3) == 0 && s < L) qkt[(int64_t)b * S + s] = tot / scale;
+        const bool writer = (lane & 3) == 0 && s < L;
+        const float score = tot / scale;
+        if (writer) qkt[(int64_t)b * S + s] = score;
+        if (st.stats != nullptr) stats_accumulate(score, writer, run_m, run_l);
+    }
+    if (st.stats != nullptr) {
+        if (lane == 0) wave_stats[wave] = make_float2(run_m, run_l);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = -INFINITY;
+            for (int w = 0; w < kBfWaves; ++w) m = fmaxf(m, wave_stats[w].x);
+            float l = 0.f;
+            for (int w = 0; w < kBfWaves; ++w)
+                if (wave_stats[w].x != -INFINITY) l += wave_stats[w].y * expf(wave_stats[w].x - m);
+            st.stats[(int64_t)b * st.per_row + blockIdx.y] = make_float2(m, l);
+        }
     }
 }
 
-// grid = (B, nchunks, d_slices); a slice covers 64 * NJ lane-units of 8 elements
+// grid = (B, nchunks); rows wider than one slice (64 * NJ lane-units of 8 elements) are swept slice by slice
 template <int NJ, bool NT>
 __global__ __launch_bounds__(kBfThreads) void softmax_v_partial_bf16_kernel(
-    const float* __restrict__ probs, const uint16_t* const* __restrict__ page_table, const int* __restrict__ lengths,
-    float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct) {
+    float* __restrict__ probs, const uint16_t* const* __restrict__ page_table, const int* __restrict__ lengths,
+    float* __restrict__ dst, int S, int D, int ct, int nchunk_max, int direct, SoftmaxStats st) {
     constexpr int kSliceU = kWave * NJ;  // lane-units (of 8 elements) per slice
     constexpr int TB = 8;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -117,36 +137,41 @@ __global__ __launch_bounds__(kBfThreads) void softmax_v_partial_bf16_kernel(
     const int L = min(lengths[b], S);
     const int s0 = c * ct;
     const int D8 = D >> 3;
-    const int u0 = blockIdx.z * kSliceU;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
+    const bool fused = st.stats != nullptr;
+    float* prow = probs + (int64_t)b * S + s0;
+    const int span = min(ct, S - s0);
 
     if (s0 >= L) {
+        if (fused) for (int i = threadIdx.x; i < span; i += kBfThreads) prow[i] = 0.f;
         if (direct && c == 0) {
             float* o = dst + (int64_t)b * D;
-            for (int i = threadIdx.x; i < kSliceU * 8; i += kBfThreads)
-                if (u0 * 8 + i < D) o[u0 * 8 + i] = 0.f;
+            for (int i = threadIdx.x; i < D; i += kBfThreads) o[i] = 0.f;
         }
         return;
     }
     const int s1 = min(s0 + ct, L);
     const int ntok = s1 - s0;
     const int ngroups = (ntok + kPage - 1) / kPage;
-    for (int i = threadIdx.x; i < ntok; i += kBfThreads) p_sh[i] = probs[(int64_t)b * S + s0 + i];
+    if (fused) {
+        float m, l;
+        stats_merge_row(st, b, L, lane, m, l);
+        const float inv_l = 1.f / l;
+        for (int i = threadIdx.x; i < span; i += kBfThreads) {
+            const float p = i < ntok ? expf(prow[i] - m) * inv_l : 0.f;
+            prow[i] = p;
+            if (i < ntok) p_sh[i] = p;
+        }
+    } else {
+        for (int i = threadIdx.x; i < ntok; i += kBfThreads) p_sh[i] = prow[i];
+    }
     for (int i = threadIdx.x; i < ngroups; i += kBfThreads)
         ptr_sh[i] = page_table[(int64_t)b * (S / kPage) + s0 / kPage + i];
     __syncthreads();
 
-    float acc[NJ][8];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-    bool live[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) live[j] = (u0 + lane + j * kWave) < D8;
-    const unsigned lane_bytes = (unsigned)(u0 + lane) * 16u;
     const int64_t row_bytes = (int64_t)3 * D * 2;
+    float* o = direct ? dst + (int64_t)b * D : dst + ((int64_t)b * nchunk_max + c) * D;
 
     auto fma8 = [](float p, const u32x4_t& v, float (&a)[8]) {
         a[0] = fmaf(p, lo_bf16(v.x), a[0]); a[1] = fmaf(p, hi_bf16(v.x), a[1]);
@@ -155,49 +180,60 @@ __global__ __launch_bounds__(kBfThreads) void softmax_v_partial_bf16_kernel(
         a[6] = fmaf(p, lo_bf16(v.w), a[6]); a[7] = fmaf(p, hi_bf16(v.w), a[7]);
     };
 
-    for (int g = wave; g < ngroups; g += kBfWaves) {
-        const char* base = reinterpret_cast<const char*>(wave_uniform16(ptr_sh[g]) + 2 * (int64_t)D);  // segment 2
-        const int nt = min(kPage, ntok - g * kPage);
-        const float* pg = p_sh + g * kPage;
-        if (nt == kPage) {
+    for (int u0 = 0; u0 < D8; u0 += kSliceU) {
+        float acc[NJ][8];
+        bool live[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+            live[j] = (u0 + lane + j * kWave) < D8;
+        }
+        const unsigned lane_bytes = (unsigned)(u0 + lane) * 16u;
+        for (int g = wave; g < ngroups; g += kBfWaves) {
+            const char* base = reinterpret_cast<const char*>(wave_uniform16(ptr_sh[g]) + 2 * (int64_t)D);  // segment 2
+            const int nt = min(kPage, ntok - g * kPage);
+            const float* pg = p_sh + g * kPage;
+            if (nt == kPage) {
 #pragma unroll 1
-            for (int h = 0; h < kPage / TB; ++h) {
-                u32x4_t vb[TB][NJ];
+                for (int h = 0; h < kPage / TB; ++h) {
+                    u32x4_t vb[TB][NJ];
 #pragma unroll
-                for (int t = 0; t < TB; ++t)
+                    for (int t = 0; t < TB; ++t)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            if (live[j]) vb[t][j] = ldg_u4<NT>(byte_off(base + (h * TB + t) * row_bytes, lane_bytes + j * kWave * 16u));
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        const float p = pg[h * TB + t];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            if (live[j]) fma8(p, vb[t][j], acc[j]);
+                    }
+                }
+            } else {
+                for (int t = 0; t < nt; ++t) {
+                    const float p = pg[t];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        if (live[j]) vb[t][j] = ldg_u4<NT>(byte_off(base + (h * TB + t) * row_bytes, lane_bytes + j * kWave * 16u));
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    const float p = pg[h * TB + t];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        if (live[j]) fma8(p, vb[t][j], acc[j]);
+                        if (live[j]) fma8(p, ldg_u4<NT>(byte_off(base + t * row_bytes, lane_bytes + j * kWave * 16u)), acc[j]);
                 }
             }
-        } else {
-            for (int t = 0; t < nt; ++t) {
-                const float p = pg[t];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (live[j]) fma8(p, ldg_u4<NT>(byte_off(base + t * row_bytes, lane_bytes + j * kWave * 16u)), acc[j]);
-            }
         }
-    }
-    // cross-wave sum through LDS, element-major so the final stores are contiguous floats
+        // cross-wave sum through LDS, element-major so the final stores are contiguous floats
+        if (u0 > 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave * kSliceU * 8 + (lane + j * kWave) * 8 + e] = acc[j][e];
-    __syncthreads();
-    float* o = direct ? dst + (int64_t)b * D : dst + ((int64_t)b * nchunk_max + c) * D;
-    for (int i = threadIdx.x; i < kSliceU * 8; i += kBfThreads) {
-        if (u0 * 8 + i < D) {
-            float r = red[i];
+            for (int e = 0; e < 8; ++e) red[wave * kSliceU * 8 + (lane + j * kWave) * 8 + e] = acc[j][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < kSliceU * 8; i += kBfThreads) {
+            if (u0 * 8 + i < D) {
+                float r = red[i];
 #pragma unroll
-            for (int w = 1; w < kBfWaves; ++w) r += red[w * kSliceU * 8 + i];
-            o[u0 * 8 + i] = r;
+                for (int w = 1; w < kBfWaves; ++w) r += red[w * kSliceU * 8 + i];
+                o[u0 * 8 + i] = r;
+            }
         }
     }
 }
@@ -205,47 +241,79 @@ __global__ __launch_bounds__(kBfThreads) void softmax_v_partial_bf16_kernel(
 int launch_softmax_v_combine(const float* partial, const int* lengths, float* out, int B, int S, int D, int ct,
                              int nchunk, hipStream_t st);  // attention_scan.hip
 
-int launch_qkt_paged_bf16(const float* q, const uint16_t* const* page_table, const int* lengths, float* qkt,
-                          int B, int S, int D, hipStream_t st) {
+static const SoftmaxStats kNoStatsBf{nullptr, 0, 0};
+
+static int launch_qkt_paged_bf16_stats(const float* q, const uint16_t* const* page_table, const int* lengths,
+                                       float* qkt, int B, int S, int D, SoftmaxStats stats, hipStream_t st) {
     if (S % kPage != 0 || D % 8 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
     const int ct = chunk_tokens_for(B, S);
     const size_t smem = (size_t)D * 4 + (size_t)(ct / kPage) * 8;
     dim3 grid(B, ceil_div_i(S, ct));
     if (nt_loads_enabled())
-        hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, true>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct);
+        hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, true>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct, stats);
     else
-        hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, false>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct);
+        hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, false>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct, stats);
     return launch_status();
 }
 
-int launch_softmax_v_paged_bf16(const float* probs, const uint16_t* const* page_table, const int* lengths, float* out,
-                                int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
+int launch_qkt_paged_bf16(const float* q, const uint16_t* const* page_table, const int* lengths, float* qkt,
+                          int B, int S, int D, hipStream_t st) {
+    return launch_qkt_paged_bf16_stats(q, page_table, lengths, qkt, B, S, D, kNoStatsBf, st);
+}
+
+static int launch_softmax_v_paged_bf16_stats(float* probs, const uint16_t* const* page_table, const int* lengths,
+                                             float* out, int B, int S, int D, void* workspace, size_t ws_bytes,
+                                             SoftmaxStats stats, hipStream_t st) {
     if (S % kPage != 0 || D % 8 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
     const int D8 = D / 8;
     const int nj = min(2, ceil_div_i(D8, kWave));
     const int slice_u = kWave * nj;
-    const int nslices = ceil_div_i(D8, slice_u);
     const int ct = chunk_tokens_for(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     float* dst = out;
     if (!direct) {
-        const size_t need = (size_t)B * nchunk * D * sizeof(float);
+        const size_t need = stats_region_bytes_for(B, S) + (size_t)B * nchunk * D * sizeof(float);
         if (workspace == nullptr || ws_bytes < need) return MLI_ERR_WORKSPACE;
-        dst = reinterpret_cast<float*>(workspace);
+        dst = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + stats_region_bytes_for(B, S));
     }
     const size_t smem = (size_t)ct * 4 + (size_t)(ct / kPage) * 8 + (size_t)kBfWaves * slice_u * 8 * 4;
-    dim3 grid(B, nchunk, nslices);
+    dim3 grid(B, nchunk);
     const bool nt = nt_loads_enabled();
 #define MLI_SVB_LAUNCH(NJ, NT)                                                                             \
     hipLaunchKernelGGL((softmax_v_partial_bf16_kernel<NJ, NT>), grid, dim3(kBfThreads), smem, st, probs, page_table, \
-                       lengths, dst, S, D, ct, nchunk, direct)
+                       lengths, dst, S, D, ct, nchunk, direct, stats)
     if (nj == 1) { if (nt) MLI_SVB_LAUNCH(1, true); else MLI_SVB_LAUNCH(1, false); }
     else { if (nt) MLI_SVB_LAUNCH(2, true); else MLI_SVB_LAUNCH(2, false); }
 #undef MLI_SVB_LAUNCH
     int rc = launch_status();
     if (rc || direct) return rc;
-    return launch_softmax_v_combine(reinterpret_cast<const float*>(workspace), lengths, out, B, S, D, ct, nchunk, st);
+    return launch_softmax_v_combine(dst, lengths, out, B, S, D, ct, nchunk, st);
+}
+
+int launch_softmax_v_paged_bf16(const float* probs, const uint16_t* const* page_table, const int* lengths, float* out,
+                                int B, int S, int D, void* workspace, size_t ws_bytes, hipStream_t st) {
+    return launch_softmax_v_paged_bf16_stats(const_cast<float*>(probs), page_table, lengths, out, B, S, D, workspace,
+                                             ws_bytes, kNoStatsBf, st);
+}
+
+int launch_scores_softmax_v_paged_bf16(const float* q, const uint16_t* const* page_table, const int* lengths,
+                                       float* qkt, float* out, int B, int S, int D, void* ws, size_t ws_bytes,
+                                       hipStream_t st) {
+    if (!fused_softmax_wanted(B, S) || ws == nullptr || ws_bytes < stats_region_bytes_for(B, S) ||
+        ceil_div_i(S, chunk_tokens_for(B, S)) > 256) {
+        int rc = launch_qkt_paged_bf16(q, page_table, lengths, qkt, B, S, D, st);
+        if (!rc) rc = launch_softmax(qkt, lengths, B, S, st);
+        if (!rc) rc = launch_softmax_v_paged_bf16(qkt, page_table, lengths, out, B, S, D, ws, ws_bytes, st);
+        return rc;
+    }
+    SoftmaxStats stats;
+    stats.stats = reinterpret_cast<float2*>(ws);
+    stats.per_row = ceil_div_i(S, 64);
+    stats.chunk_tokens = chunk_tokens_for(B, S);
+    int rc = launch_qkt_paged_bf16_stats(q, page_table, lengths, qkt, B, S, D, stats, st);
+    if (rc) return rc;
+    return launch_softmax_v_paged_bf16_stats(qkt, page_table, lengths, out, B, S, D, ws, ws_bytes, stats, st);
 }
 
 }  // namespace mli

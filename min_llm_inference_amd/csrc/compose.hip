@@ -19,6 +19,12 @@ int launch_softmax(float*, const int*, int, int, hipStream_t);
 int launch_softmax_v_naive(const float*, const float*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
 int launch_softmax_v_paged(const float*, const float* const*, const int*, float*, int, int, int, void*, size_t,
                            hipStream_t);
+int launch_scores_softmax_v_paged(const float*, const float* const*, const int*, float*, float*, int, int, int, void*,
+                                  size_t, hipStream_t);
+int launch_scores_softmax_v_naive(const float*, const float*, const float*, const int*, float*, float*, int, int, int,
+                                  void*, size_t, hipStream_t);
+int launch_scores_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*, float*, float*, int, int, int,
+                                       void*, size_t, hipStream_t);
 int launch_latest_paged_bf16(uint16_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*, float*, int,
                              int, int, hipStream_t);
 int launch_fill_paged_bf16(uint16_t* const*, const int*, const int*, const uint16_t*, const uint16_t*, int, int, int,
@@ -42,12 +48,8 @@ int mli_paged_attention_bf16(mli_bf16* const* page_table, const int* lengths, co
     if (rc) return rc;
     rc = mli::launch_latest_paged_bf16(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim, st);
     if (rc) return rc;
-    rc = mli::launch_qkt_paged_bf16(q_output, page_table, lengths, qkt_output, n_batch, n_sequence, emb_dim, st);
-    if (rc) return rc;
-    rc = mli::launch_softmax(qkt_output, lengths, n_batch, n_sequence, st);
-    if (rc) return rc;
-    return mli::launch_softmax_v_paged_bf16(qkt_output, page_table, lengths, attention_result, n_batch, n_sequence,
-                                            emb_dim, workspace, workspace_bytes, st);
+    return mli::launch_scores_softmax_v_paged_bf16(q_output, page_table, lengths, qkt_output, attention_result,
+                                                   n_batch, n_sequence, emb_dim, workspace, workspace_bytes, st);
 }
 
 int mli_inference_self_attention(const float* inp_embedding, const int* lengths, const float* wk, const float* wq,
@@ -62,12 +64,8 @@ int mli_inference_self_attention(const float* inp_embedding, const int* lengths,
     rc = mli::launch_latest_naive(inp_embedding, lengths, wk, wq, wv, kt_cache, v_cache, q_output, n_batch,
                                   n_sequence, input_dim, output_dim, st);
     if (rc) return rc;
-    rc = mli::launch_qkt_naive(q_output, kt_cache, lengths, qkt_output, n_batch, n_sequence, output_dim, st);
-    if (rc) return rc;
-    rc = mli::launch_softmax(qkt_output, lengths, n_batch, n_sequence, st);
-    if (rc) return rc;
-    return mli::launch_softmax_v_naive(qkt_output, v_cache, lengths, attention_result, n_batch, n_sequence,
-                                       output_dim, workspace, workspace_bytes, st);
+    return mli::launch_scores_softmax_v_naive(q_output, kt_cache, v_cache, lengths, qkt_output, attention_result,
+                                              n_batch, n_sequence, output_dim, workspace, workspace_bytes, st);
 }
 
 int mli_paged_attention(float* const* page_table, const int* lengths, const float* wk, const float* wq,
@@ -80,12 +78,8 @@ int mli_paged_attention(float* const* page_table, const int* lengths, const floa
     if (rc) return rc;
     rc = mli::launch_latest_paged(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim, st);
     if (rc) return rc;
-    rc = mli::launch_qkt_paged(q_output, page_table, lengths, qkt_output, n_batch, n_sequence, emb_dim, st);
-    if (rc) return rc;
-    rc = mli::launch_softmax(qkt_output, lengths, n_batch, n_sequence, st);
-    if (rc) return rc;
-    return mli::launch_softmax_v_paged(qkt_output, page_table, lengths, attention_result, n_batch, n_sequence,
-                                       emb_dim, workspace, workspace_bytes, st);
+    return mli::launch_scores_softmax_v_paged(q_output, page_table, lengths, qkt_output, attention_result, n_batch,
+                                              n_sequence, emb_dim, workspace, workspace_bytes, st);
 }
 
 }  // extern "C"

@@ -116,6 +116,43 @@ __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
     return d;
 }
 
+// ---- softmax statistics shared by the fused qkt / softmax.V kernels (see attention_scan.hip) ----------------
+struct SoftmaxStats {
+    float2* stats;      // [B][per_row] (max, sum exp(score - max)); nullptr = not fused
+    int per_row;        // entries per row
+    int chunk_tokens;   // tokens covered by one entry
+};
+
+// online (max, sum-exp) update of one wave with the scores its lanes hold (valid lanes only)
+__device__ __forceinline__ void stats_accumulate(float score, bool valid, float& m, float& l) {
+    const float pm = wave_max(valid ? score : -INFINITY);
+    const float m_new = fmaxf(m, pm);
+    const float ps = wave_sum(valid ? expf(score - m_new) : 0.f);
+    l = (m == -INFINITY ? 0.f : l * expf(m - m_new)) + ps;
+    m = m_new;
+}
+
+// row-level (m, l) from the row's chunk statistics: lanes read entries in parallel, two wave reductions;
+// every wave of the workgroup does this redundantly (no barrier needed), every lane gets the same values
+__device__ __forceinline__ void stats_merge_row(const SoftmaxStats& st, int b, int L, int lane, float& m, float& l) {
+    const int n = (L + st.chunk_tokens - 1) / st.chunk_tokens;
+    const float2* row = st.stats + (int64_t)b * st.per_row;
+    float2 mine[4];  // up to 256 chunks per row (n_sequence <= 16384 at the smallest chunk)
+    float lm = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + k * kWave;
+        mine[k] = i < n ? row[i] : make_float2(-INFINITY, 0.f);
+        lm = fmaxf(lm, mine[k].x);
+    }
+    m = wave_max(lm);
+    float ls = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (mine[k].x != -INFINITY) ls += mine[k].y * expf(mine[k].x - m);
+    l = wave_sum(ls);
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int launch_status() {

@@ -40,8 +40,8 @@ def test_arity_matches_header():
 
 def test_abi_version_and_workspace_query(mli):
     assert mli.mli_abi_version() == 2
-    assert mli.mli_attention_workspace_bytes(4, 64, 64) == 0           # single chunk: no scratch
-    assert mli.mli_attention_workspace_bytes(1024, 4096, 512) == 1024 * 64 * 512 * 4
+    assert mli.mli_attention_workspace_bytes(4, 64, 64) == 256         # single chunk: softmax statistics only
+    assert mli.mli_attention_workspace_bytes(1024, 4096, 512) == 1024 * 64 * 8 + 1024 * 64 * 512 * 4
     assert mli.mli_attention_workspace_bytes(0, 4096, 512) == 0
 
 

@@ -86,15 +86,18 @@ def test_softmax_v(oracle, mli, dev, seed, B, S, Din, Dout):
     assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
 
 
-@pytest.mark.parametrize("conditioned,zero_every", [(False, None), (True, 5), (True, None), (False, 5)])
+@pytest.mark.parametrize("conditioned,zero_every,fused", [(False, None, 1), (True, 5, 1), (True, None, 0), (False, 5, 0)])
 @pytest.mark.parametrize("seed,B,S,Din,Dout", SHAPES)
-def test_inference_self_attention(oracle, mli, dev, seed, B, S, Din, Dout, zero_every, conditioned):
-    """reference tests InferenceOptimizedSelfAttentionTest / ...ZeroLengthTest (…_test.cpp:139-190)."""
+def test_inference_self_attention(oracle, mli, dev, seed, B, S, Din, Dout, zero_every, conditioned, fused):
+    """reference tests InferenceOptimizedSelfAttentionTest / ...ZeroLengthTest (…_test.cpp:139-190);
+    fused = 1 / 0 forces the softmax-fused / three-launch form of the composition."""
     from min_llm_inference_amd import ops
+    assert mli.mli_tune(b"fused_softmax", fused) == 0
     c = naive_case(seed, B, S, Din, Dout, conditioned=conditioned, zero_every=zero_every)
     d = to_dev(c, dev)
     ops.inference_self_attention(d["inp"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["kt_cache"],
                                  d["v_cache"], d["q_output"], d["qkt_output"], d["attention_result"], c["n_new"])
+    mli.mli_tune(b"fused_softmax", -1)
     oracle.self_attention_inference_host(c["inp"], c["lengths"], c["wk"], c["wq"], c["wv"], c["new_batch_idx"],
                                          c["kt_cache"], c["v_cache"], c["q_output"], c["qkt_output"],
                                          c["attention_result"], c["n_new"])

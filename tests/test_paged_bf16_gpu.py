@@ -38,15 +38,16 @@ def _bits_within_one_ulp(got, want):
     return (np.abs(g - w) <= 2.0 ** -7 * np.abs(w) + 1e-5).all()
 
 
-@pytest.mark.parametrize("native", [1, 0])
+@pytest.mark.parametrize("native,fused", [(1, 1), (0, 0), (1, 0)])
 @pytest.mark.parametrize("zero_every", [None, 4])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
-def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every, native):
+def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every, native, fused):
     """native=1: v_mfma_f32_32x32x16_bf16 (the hardware sums the 16 products of a step in its own order, so q and
     the stored K/V may differ from the sequential fp32 oracle by fp32 rounding: q within 1e-4, K/V bits within one
     bf16 ulp).  native=0: fp32-widened operands, bit-exact."""
     from min_llm_inference_amd import ops
     assert mli.mli_tune(b"bf16_native_mfma", native) == 0
+    assert mli.mli_tune(b"fused_softmax", fused) == 0
     c, d = _case(oracle, dev, seed, B, S, D, zero_every)
     ops.paged_attention_bf16(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"],
                              d["q_output"], d["qkt_output"], d["attention_result"], c["n_new"], S)
@@ -62,6 +63,7 @@ def test_paged_attention_bf16(oracle, mli, dev, seed, B, S, D, zero_every, nativ
     oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
 
     mli.mli_tune(b"bf16_native_mfma", 1)
+    mli.mli_tune(b"fused_softmax", -1)
     if native:
         assert_close(host(d["q_output"]), c["q_output"], thr=1e-4, what="q_output")
     else:

@@ -103,16 +103,19 @@ def test_softmax_v(oracle, mli, dev, seed, B, S, D):
     assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
 
 
-@pytest.mark.parametrize("conditioned,zero_every,variant", [
-    (False, None, "paged_attention"), (True, 5, "paged_attention"),
-    (True, None, "paged_attention_with_cublas"), (False, 5, "paged_attention_with_cublas")])
+@pytest.mark.parametrize("conditioned,zero_every,variant,fused", [
+    (False, None, "paged_attention", 1), (True, 5, "paged_attention", 1), (True, 5, "paged_attention", 0),
+    (True, None, "paged_attention_with_cublas", 0), (False, 5, "paged_attention_with_cublas", 1)])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
-def test_paged_attention_composition(oracle, mli, dev, seed, B, S, D, zero_every, conditioned, variant):
-    """reference InferenceOptimizedSelfAttentionTest / ...ZeroLengthTest (paged_attention_kernels_test.cpp:114-233)."""
+def test_paged_attention_composition(oracle, mli, dev, seed, B, S, D, zero_every, conditioned, variant, fused):
+    """reference InferenceOptimizedSelfAttentionTest / ...ZeroLengthTest (paged_attention_kernels_test.cpp:114-233).
+    fused = 1 / 0 forces the softmax-fused and the three-launch form of the composition (mli_tune)."""
     from min_llm_inference_amd import ops
+    assert mli.mli_tune(b"fused_softmax", fused) == 0
     c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=zero_every, conditioned=conditioned)
     getattr(ops, variant)(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["q_output"],
                           d["qkt_output"], d["attention_result"], c["n_new"], S)
+    mli.mli_tune(b"fused_softmax", -1)
     oracle.self_attention_inference_host(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"],
                                          c["new_batch_idx"], c["kt_cache"], c["v_cache"], c["q_output"],
                                          c["qkt_output"], c["attention_result"], c["n_new"])
