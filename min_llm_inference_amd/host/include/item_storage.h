@@ -77,3 +77,7 @@ int insert_new_items(const std::vector<int>& finished_indices, TensorInt& inp_de
                      ProcessingStorage& processing_storage);
 
 bool is_done(ItemStorage& item_storage, ProcessingStorage& processing_storage);
+
+// Extension: upload inp rows `slots` (lengths[slot] tokens each) with as few copies as possible.
+void upload_changed_rows(TensorInt& inp_device, TensorInt& inp_host, const std::vector<int>& slots,
+                         const int* lengths, int n_sequence);

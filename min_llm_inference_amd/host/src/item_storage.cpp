@@ -65,6 +65,23 @@ bool is_done(ItemStorage& item_storage, ProcessingStorage& processing_storage) {
     return processing_storage.size() == 0 && item_storage.new_count() == 0;
 }
 
+// Upload the token prefixes of the rows that changed.  A few rows: one small copy each (only the prompt);
+// many rows: one copy spanning first..last changed row -- every hipMemcpy costs ~5 us of host time, so
+// hundreds of per-row copies would dominate an iteration (the reference copies all of inp[B, S] every time).
+void upload_changed_rows(TensorInt& inp_device, TensorInt& inp_host, const std::vector<int>& slots,
+                         const int* lengths, int n_sequence) {
+    if (slots.empty()) return;
+    if (slots.size() <= 4) {
+        for (int slot : slots)
+            inp_device.copy_range_from(inp_host, static_cast<size_t>(slot) * n_sequence, static_cast<size_t>(lengths[slot]));
+        return;
+    }
+    const auto mm = std::minmax_element(slots.begin(), slots.end());
+    const size_t first = static_cast<size_t>(*mm.first) * n_sequence;
+    const size_t last = static_cast<size_t>(*mm.second) * n_sequence + static_cast<size_t>(lengths[*mm.second]);
+    inp_device.copy_range_from(inp_host, first, last - first);
+}
+
 // ---- per-iteration host steps -------------------------------------------------------------------------
 std::vector<int> process_decoder_result(const TensorInt& decoder_result_device, TensorInt& decoder_result_host,
                                         ItemStorage& item_storage, ProcessingStorage& processing_storage,
@@ -116,6 +133,7 @@ int insert_new_items(const std::vector<int>& finished_indices, TensorInt& inp_de
         lengths[b] = processing_storage.batch_id_processing(b)
                          ? static_cast<int>(processing_storage.get_token(b).second.size()) : 0;
 
+    std::vector<int> filled;
     for (size_t i = 0; i < finished_indices.size(); ++i) {
         const int slot = finished_indices[i];
         new_idx[i] = slot;
@@ -127,10 +145,10 @@ int insert_new_items(const std::vector<int>& finished_indices, TensorInt& inp_de
         assert(static_cast<int>(toks.size()) + 1 <= n_sequence);
         lengths[slot] = static_cast<int>(toks.size());
         std::copy(toks.begin(), toks.end(), inp + static_cast<size_t>(slot) * n_sequence);
-        // upload only this row's prompt instead of the whole inp[B, S]
-        inp_device.copy_range_from(inp_host, static_cast<size_t>(slot) * n_sequence, toks.size());
+        filled.push_back(slot);
         processing_storage.put(slot, std::move(fresh[i]));
     }
+    upload_changed_rows(inp_device, inp_host, filled, lengths, n_sequence);
     lengths_device.copy_from(lengths_host);
     new_items_indices_device.copy_from(new_items_indices_host);
     return static_cast<int>(fresh.size());

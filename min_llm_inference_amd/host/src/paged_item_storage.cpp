@@ -157,13 +157,13 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
         assert(n_tokens + 1 <= n_sequence);
         lengths[slot] = n_tokens;
         std::copy(item.second.begin(), item.second.end(), inp + static_cast<size_t>(slot) * n_sequence);
-        inp_device.copy_range_from(inp_host, static_cast<size_t>(slot) * n_sequence, item.second.size());
         new_idx[inserted.size()] = slot;
         const int n_pages = std::min(width, std::max(ceil_div(n_tokens + n_forward_rounds, PAGE_BLOCK_SIZE), DEFAULT_INIT_NUM_BLOCKS));
         processing_storage.put(slot, std::move(item));
         pages.add_batch_block_pair(std::make_pair(slot, pool.pop_free_blocks(n_pages)));
         inserted.push_back(slot);
     }
+    upload_changed_rows(inp_device, inp_host, inserted, lengths, n_sequence);
     if (dirty) {
         lengths_device.copy_from(lengths_host);
         new_items_indices_device.copy_from(new_items_indices_host);

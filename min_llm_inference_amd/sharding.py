@@ -22,14 +22,46 @@ def shard_items(items, rank, world):
 
 
 class TokenGather:
-    """Per-step all-gather of the ranks' decoder outputs into one [world * rows_per_rank] int32 tensor."""
+    """Per-step all-gather of the ranks' decoder outputs into one [world * rows_per_rank] int32 tensor.
 
-    def __init__(self, rows_per_rank, world, device):
+    The gather is asynchronous: the next decode step does not depend on the other ranks' tokens (only the host
+    scheduler consumes them), so the collective runs on the communicator's stream beside the next step's
+    kernels.  Callers alternate between `depth` input buffers (see buffer()) so a step never overwrites tokens
+    that are still being gathered; wait() drains everything."""
+
+    def __init__(self, rows_per_rank, world, device, depth=2):
         self.world = world
-        self.out = torch.empty(world * rows_per_rank, dtype=torch.int32, device=device) if world > 1 else None
+        self.depth = depth
+        self.step = 0
+        self.inputs = [torch.full((rows_per_rank,), -1, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.outputs = [torch.empty(world * rows_per_rank, dtype=torch.int32, device=device) for _ in range(depth)] \
+            if world > 1 else None
+        self.pending = [None] * depth
 
-    def __call__(self, local_tokens):
+    def buffer(self):
+        """The decoder-result buffer to fill in the current step (its previous gather has completed)."""
+        slot = self.step % self.depth
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        return self.inputs[slot]
+
+    def __call__(self):
+        """Start gathering the buffer handed out by buffer() for this step."""
+        slot = self.step % self.depth
+        self.step += 1
         if self.world == 1:
-            return local_tokens
-        dist.all_gather_into_tensor(self.out, local_tokens.contiguous().view(-1))
-        return self.out
+            return self.inputs[slot]
+        self.pending[slot] = dist.all_gather_into_tensor(self.outputs[slot], self.inputs[slot], async_op=True)
+        return self.outputs[slot]
+
+    def wait(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+    def latest(self):
+        """Gathered tokens of the most recent step (after wait())."""
+        slot = (self.step - 1) % self.depth
+        return self.inputs[slot] if self.world == 1 else self.outputs[slot]

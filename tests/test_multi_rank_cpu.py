@@ -34,7 +34,10 @@ def _worker(rank, world, port, out_dir):
     steps = []
     while True:
         local = torch.from_numpy(eng.step() if not eng.done() else np.full((hi - lo,), -1, np.int32))
-        steps.append(gather(local).clone().numpy())
+        gather.buffer().copy_(local)   # the engine's decoder output for this step
+        gather()                       # asynchronous all-gather; overlaps the next step on GPUs
+        gather.wait()
+        steps.append(gather.latest().clone().numpy())
         flag = torch.tensor([0 if eng.done() else 1])
         dist.all_reduce(flag)  # keep stepping until every rank is done (lockstep, as bench.py does)
         if flag.item() == 0:
