@@ -231,6 +231,21 @@ def cpu_baseline(wl, budget_s=12.0):
                       f"single-threaded oracle_cpu.c"}
 
 
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gemm_report(wl, lengths, times):
+    """MFMA utilisation of the decode projection x[B,D].[Wk|Wq|Wv] (gather-GEMM-scatter kernel)."""
+    live = int((lengths > 0).sum())
+    flops = 2.0 * live * wl.D * 3 * wl.D
+    ms = [v for k, v in times.items() if k.startswith("get_latest")][0]
+    tf = flops / (ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[wl.dtype]
+    return {"bound": "mfma", "flops_per_launch": flops, "avg_launch_ms": ms, "achieved": tf, "peak": peak,
+            "unit": "TFLOP/s", "frac": tf / peak,
+            "note": "1.6 GFLOP per launch at B=1024, D=512: latency-bound, 2 % of the step"}
+
+
 def pmc_traffic(workload, which, layout, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this command
     (profiles/pmc_<workload>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE).  bench.py cannot
@@ -409,6 +424,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms,
             "kernel_ms": times,
+            "projection_gemm": gemm_report(wl, lengths_now, times),
             "step_algorithmic_bytes": alg["step"],
             "step_gbs": alg["step"] / (out["ms_per_step"] * 1e-3) / 1e9,
             "measured_copy_gbs": measure_copy_gbs(dev),

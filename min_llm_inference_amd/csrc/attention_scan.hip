@@ -201,20 +201,22 @@ __global__ __launch_bounds__(kScanThreads) void qkt_naive_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Masked softmax in place, one wave per row, float4 traffic.  block = 256 (4 rows).
+// Masked softmax in place.  One workgroup (4 waves) per row, float4 traffic; only the live prefix is read,
+// the tail is zero-filled.  grid = B.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanThreads) void softmax_lengths_kernel(
     float* __restrict__ qkt, const int* __restrict__ lengths, int B, int S) {
-    const int row = blockIdx.x * kScanWaves + (threadIdx.x >> 6);
-    if (row >= B) return;
+    __shared__ float wave_part[kScanWaves];
+    const int row = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
     const int L = min(lengths[row], S);
     float4* rp = reinterpret_cast<float4*>(qkt + (int64_t)row * S);
     const int n4_len = (L + 3) >> 2;
     const int n4 = S >> 2;
 
     float m = -INFINITY;
-    for (int i = lane; i < n4_len; i += kWave) {
+    for (int i = threadIdx.x; i < n4_len; i += kScanThreads) {
         const float4 v = rp[i];
         const int s = i * 4;
         m = fmaxf(m, v.x);
@@ -223,8 +225,12 @@ __global__ __launch_bounds__(kScanThreads) void softmax_lengths_kernel(
         if (s + 3 < L) m = fmaxf(m, v.w);
     }
     m = wave_max(m);
+    if (lane == 0) wave_part[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wave_part[0], wave_part[1]), fmaxf(wave_part[2], wave_part[3]));
+    __syncthreads();
     float sum = 0.f;
-    for (int i = lane; i < n4_len; i += kWave) {
+    for (int i = threadIdx.x; i < n4_len; i += kScanThreads) {
         const float4 v = rp[i];
         const int s = i * 4;
         sum += expf(v.x - m);
@@ -233,7 +239,10 @@ __global__ __launch_bounds__(kScanThreads) void softmax_lengths_kernel(
         if (s + 3 < L) sum += expf(v.w - m);
     }
     sum = wave_sum(sum);
-    for (int i = lane; i < n4; i += kWave) {
+    if (lane == 0) wave_part[wave] = sum;
+    __syncthreads();
+    sum = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
+    for (int i = threadIdx.x; i < n4; i += kScanThreads) {
         const int s = i * 4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < L) {
@@ -519,8 +528,7 @@ int launch_qkt_naive(const float* q, const float* kt, const int* lengths, float*
 
 int launch_softmax(float* qkt, const int* lengths, int B, int S, hipStream_t st) {
     if (S % 4 != 0 || B <= 0) return MLI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(softmax_lengths_kernel, dim3(ceil_div_i(B, kScanWaves)), dim3(kScanThreads), 0, st,
-                       qkt, lengths, B, S);
+    hipLaunchKernelGGL(softmax_lengths_kernel, dim3(B), dim3(kScanThreads), 0, st, qkt, lengths, B, S);
     return launch_status();
 }
 

@@ -32,6 +32,32 @@ __global__ __launch_bounds__(256) void read_rows(const float4* __restrict__ src,
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gv4_ptr;
+
+// each wave streams its own contiguous region of `bytes_per_wave`, UNROLL x 1 KiB in flight, optional nt hint
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void read_regions(const float4* __restrict__ src, float* __restrict__ sink,
+                                                     long n4, long f4_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.f;
+    for (long base = wave * f4_per_wave; base + f4_per_wave <= n4; base += nwaves * f4_per_wave) {
+        for (long o = 0; o < f4_per_wave; o += 64 * UNROLL) {
+            f32x4_t v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                gv4_ptr p = (gv4_ptr)(src + base + o + u * 64 + lane);
+                v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 template <int UNROLL>
 __global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x);
@@ -74,6 +100,17 @@ int main() {
         printf("copy unroll8 grid  4096: %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
         ms = time_ms([&] { CK(hipMemcpyAsync(dst, src, n4 * 16, hipMemcpyDeviceToDevice, 0)); }, 5);
         printf("hipMemcpy D2D         : %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
+    }
+    for (long kib : {16, 64, 256}) {
+        const long f4w = kib * 64;                      // float4 per wave region
+        if (f4w % (64 * 16) != 0 || f4w > n4) continue;  // a region must hold whole UNROLL=16 batches (bounds!)
+        for (int grid : {2048, 8192}) {
+            float a = time_ms([&] { hipLaunchKernelGGL((read_regions<4, false>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
+            float b = time_ms([&] { hipLaunchKernelGGL((read_regions<4, true>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
+            float c = time_ms([&] { hipLaunchKernelGGL((read_regions<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
+            printf("read regions %4ld KiB/wave grid %5d: u4 %.0f  u4-nt %.0f  u16-nt %.0f GB/s\n", kib, grid,
+                   n4 * 16.0 / a / 1e6, n4 * 16.0 / b / 1e6, n4 * 16.0 / c / 1e6);
+        }
     }
     // contiguous rows of 2 KiB (128 float4): pure streaming read
     struct Shape { const char* name; int row_f4; long stride_f4; };
