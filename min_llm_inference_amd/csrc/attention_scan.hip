@@ -27,11 +27,14 @@ static int g_chunk_tokens = 0;
 static int g_nt_loads = 1;
 static int g_qkt_token_batch = 8;
 
-// Sequence chunk (tokens per workgroup) for the split-sequence kernels: the largest
-// power of two in [64, 1024] that still yields >= 16384 work units (measured on MI355X: 256 at
-// B=1024, S=4096; with rows as the fast grid dimension the choice is worth only a few percent).
+// Sequence chunk (tokens per workgroup) for the split-sequence kernels: the largest power of two in
+// [64, 1024] that still yields >= min_units work units.  With rows as the fast grid dimension the choice is
+// worth a few percent (measured on MI355X at B=1024, S=4096: q.K^T 256, softmax.V 512).
 // MLI_CHUNK_TOKENS (power of two in [64, 1024]) overrides the heuristic for tuning runs.
-static int pick_chunk_tokens(int n_batch, int n_sequence) {
+constexpr int kQktUnits = 16384;  // q.K^T is insensitive to the chunk size (341-349 us for 64..512 tokens at config 4)
+constexpr int kSvUnits = 8192;    // softmax.V prefers larger chunks: fewer partial sums to write and combine
+
+static int pick_chunk_tokens(int n_batch, int n_sequence, int min_units = kQktUnits) {
     static const int forced = [] {
         const char* e = getenv("MLI_CHUNK_TOKENS");
         const int v = e ? atoi(e) : 0;
@@ -40,7 +43,7 @@ static int pick_chunk_tokens(int n_batch, int n_sequence) {
     if (forced) return forced;
     if (g_chunk_tokens) return g_chunk_tokens;
     int ct = kMaxChunkTokens;
-    while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < 16384) ct >>= 1;
+    while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < min_units) ct >>= 1;
     return ct;
 }
 
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
 int chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence); }
+int sv_chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence, kSvUnits); }
 int nt_loads_enabled() { return g_nt_loads; }
 
 int launch_softmax_v_combine(const float* partial, const int* lengths, float* out, int B, int S, int D, int ct,
@@ -463,7 +467,7 @@ static int launch_softmax_v_impl(float* probs, const void* src, const int* lengt
     const int Dv = D / VEC;
     const int nj = min(2, ceil_div_i(Dv, kWave));  // <= 64 VGPRs -> 8 waves/SIMD; wider rows are swept in slices
     const int slice_v = kWave * nj;
-    int ct = pick_chunk_tokens(B, S);
+    int ct = pick_chunk_tokens(B, S, kSvUnits);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     float* dst = out;

@@ -10,7 +10,8 @@ namespace mli {
 constexpr int kBfThreads = 256;
 constexpr int kBfWaves = kBfThreads / kWave;
 
-int chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip (same heuristic / tuning knobs)
+int chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip (same heuristics / tuning knobs)
+int sv_chunk_tokens_for(int n_batch, int n_sequence);
 int nt_loads_enabled();
 int fused_softmax_wanted(int B, int S);
 size_t stats_region_bytes_for(int B, int S);
@@ -268,7 +269,7 @@ static int launch_softmax_v_paged_bf16_stats(float* probs, const uint16_t* const
     const int D8 = D / 8;
     const int nj = min(2, ceil_div_i(D8, kWave));
     const int slice_u = kWave * nj;
-    const int ct = chunk_tokens_for(B, S);
+    const int ct = sv_chunk_tokens_for(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     float* dst = out;

@@ -8,7 +8,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 // each wave reads `rows_per_wave` rows of `row_f4` float4 (contiguous), rows spaced `stride_f4` apart.
-template <int UNROLL>
+template <int UNROLL, bool NT = false>
 __global__ __launch_bounds__(256) void read_rows(const float4* __restrict__ src, float* __restrict__ sink,
                                                   long rows_total, int row_f4, long stride_f4) {
     const int lane = threadIdx.x & 63;
@@ -23,7 +23,17 @@ __global__ __launch_bounds__(256) void read_rows(const float4* __restrict__ src,
             for (int u = 0; u < UNROLL; ++u) {
                 long r = r0 + u;
                 int i = lane + j * 64;
-                v[u] = (r < rows_total && i < row_f4) ? src[r * stride_f4 + i] : make_float4(0, 0, 0, 0);
+                if (r < rows_total && i < row_f4) {
+                    if (NT) {
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        f4v t = __builtin_nontemporal_load((const f4v __attribute__((address_space(1)))*)(src + r * stride_f4 + i));
+                        v[u] = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        v[u] = src[r * stride_f4 + i];
+                    }
+                } else {
+                    v[u] = make_float4(0, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
@@ -115,15 +125,18 @@ int main() {
     // contiguous rows of 2 KiB (128 float4): pure streaming read
     struct Shape { const char* name; int row_f4; long stride_f4; };
     Shape shapes[] = {{"contig 2KiB rows", 128, 128}, {"2KiB @ 6KiB stride (K of fp32 pages D=512)", 128, 384},
-                      {"4KiB @ 6KiB stride (K|V of fp32 pages)", 256, 384}, {"1KiB @ 3KiB stride (D=256)", 64, 192}};
+                      {"4KiB @ 6KiB stride (K|V of fp32 pages)", 256, 384}, {"1KiB @ 3KiB stride (K of bf16 pages)", 64, 192},
+                      {"2KiB @ 3KiB stride (K|V of bf16 pages)", 128, 192}};
     for (auto& sh : shapes) {
         long rows = (n4 - sh.row_f4) / sh.stride_f4;
         for (int grid : {2048, 4096, 8192}) {
             float ms4 = time_ms([&] { hipLaunchKernelGGL(read_rows<4>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
             float ms8 = time_ms([&] { hipLaunchKernelGGL(read_rows<8>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
             float ms16 = time_ms([&] { hipLaunchKernelGGL(read_rows<16>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float nt8 = time_ms([&] { hipLaunchKernelGGL((read_rows<8, true>), dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float nt16 = time_ms([&] { hipLaunchKernelGGL((read_rows<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
             double bytes = (double)rows * sh.row_f4 * 16;
-            printf("read %-44s grid %5d: u4 %.0f  u8 %.0f  u16 %.0f GB/s\n", sh.name, grid, bytes / ms4 / 1e6, bytes / ms8 / 1e6, bytes / ms16 / 1e6);
+            printf("read %-44s grid %5d: u4 %.0f  u8 %.0f  u16 %.0f | nt u8 %.0f  nt u16 %.0f GB/s\n", sh.name, grid, bytes / ms4 / 1e6, bytes / ms8 / 1e6, bytes / ms16 / 1e6, bytes / nt8 / 1e6, bytes / nt16 / 1e6);
         }
     }
     return 0;
