@@ -88,6 +88,8 @@ class Workload:
                 n = min(chunk, self.pool.numel() - o)
                 self.pool[o:o + n] = u(n).to(self.pool.dtype)
             order = rng.permutation(total)
+            if os.environ.get("MLI_BENCH_POOL_ORDER") == "linear":  # diagnostic: pages handed out in address order
+                order = np.arange(total)
             table = np.zeros((B, W), np.int64)
             cur = 0
             base = self.pool.data_ptr()
@@ -135,6 +137,18 @@ class Workload:
     # ---- the individual kernels, for the roofline pass ------------------------------------
     def kernels(self):
         w = self
+        bf = self.dtype == "bf16"
+        if self.layout == "paged" and self.D * (2 if bf else 4) <= 2048:
+            # the composition runs the single-pass scan (mli_decode_scan_paged): time its two launches apart
+            latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
+            return {
+                "get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: latest(
+                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
+                "fused_decode_scan (q.K^T + online softmax + softmax.V, one visit per page)": lambda: ops.decode_scan_paged(
+                    w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=1),
+                "fused_decode_combine": lambda: ops.decode_scan_paged(
+                    w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=2),
+            }
         if self.dtype == "bf16":
             return {
                 "get_latest_k_q_v_paged_bf16 (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention_bf16(
@@ -172,7 +186,8 @@ class Workload:
         sv = kv_one + int(L.sum()) * 4 + live * D * 4 + ptrs + B * 4        # V + probs in, result out
         latest = live * D * (3 * e + 4) + 3 * D * D * e + B * 4 + (8 * live if self.layout == "paged" else 0)
         step = (2 * kv_one + live * (3 * D * e + D * 4) + 3 * D * D * e + B * 4 + ptrs)
-        return {"qkt": qkt, "softmax_v": sv, "get_latest": latest, "step": step}
+        scan = 2 * kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4   # K + V + q in, raw scores out
+        return {"qkt": qkt, "softmax_v": sv, "scan": scan, "get_latest": latest, "step": step}
 
 
 def time_kernel(fn, reps):
@@ -254,7 +269,7 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
-    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial"}[which]
+    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan"}[which]
     hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k]
     return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
@@ -413,8 +428,11 @@ def main():
         for name, fn in wl.kernels().items():
             times[name] = time_kernel(fn, max(10, args.steps))
         wl.lengths.copy_(torch.from_numpy(lengths_now).to(dev))
-        key_of = {"qkt": [k for k in times if k.startswith("qkt")][0],
-                  "softmax_v": [k for k in times if k.startswith("softmax_v")][0]}
+        if any(k.startswith("fused_decode_scan") for k in times):
+            key_of = {"scan": [k for k in times if k.startswith("fused_decode_scan")][0]}
+        else:
+            key_of = {"qkt": [k for k in times if k.startswith("qkt")][0],
+                      "softmax_v": [k for k in times if k.startswith("softmax_v")][0]}
         dom = max(key_of, key=lambda k: times[key_of[k]])
         ms = times[key_of[dom]]
         achieved = alg[dom] / (ms * 1e-3) / 1e9

@@ -171,6 +171,16 @@ int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* 
                                         int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
                                         int n_decoder_results, int i_decoder, void* stream);
 
+/* The single-pass scan the paged compositions run after the projection (scores + masked softmax + softmax.V in
+ * one visit per page; what A10 -> A4 -> A11 of SURVEY 8(a) compute together).  Inputs: q_output from
+ * mli_get_latest_k_q_v_paged[_bf16]; outputs: qkt_output (probabilities, zero tail) and attention_result.
+ * elem_bf16 selects the page element type; phases: 1 = scan kernel only, 2 = combine kernel only, 3 = both
+ * (1 and 2 exist so the two launches can be timed apart).  Returns MLI_ERR_BAD_ARG when emb_dim needs more
+ * than two 16-byte lane loads per row (fp32 > 512, bf16 > 1024): use the separate entry points then. */
+int mli_decode_scan_paged(const float* q_output, const void* const* page_table, const int* lengths,
+                          float* qkt_output, float* attention_result, int n_batch, int n_sequence, int emb_dim,
+                          int elem_bf16, int phases, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Encoder / decoder head (needed for InferenceModel::forward).
  * ---------------------------------------------------------------------------------- */
@@ -215,7 +225,10 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      split-sequence kernels
  *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
  *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch
- *   "fused_softmax"    1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
+ *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
+ *                      once for K and V, online softmax) when emb_dim fits two lane-loads per row (fp32 <= 512,
+ *                      bf16 <= 1024); 0 = separate q.K^T / softmax / softmax.V passes
+ *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
  *                      launches as the reference (qkt, softmax_in_place_with_lengths, softmax_v), -1 (default) =
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
  *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mli_paged_attention_bf16": [_P] * 9 + [_I] * 4 + [_P, _Z, _P],
     "mli_paged_attention_encoder_bf16": [_P] * 6 + [_I] * 4 + [_P],
     "mli_paged_decoder_multi_rounds_bf16": [_P] * 7 + [_I] * 6 + [_P],
+    "mli_decode_scan_paged": [_P] * 5 + [_I] * 5 + [_P, _Z, _P],
     "mli_inference_optimized_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_paged_attention_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_decoder": [_P] * 7 + [_I] * 4 + [_P],

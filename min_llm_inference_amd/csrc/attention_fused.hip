@@ -1,0 +1,381 @@
+// Single-pass decode attention over paged KV ("flash-decoding" form) used by the paged_attention compositions:
+// every page is visited ONCE and both its K rows and its V rows are consumed in that visit, with an online
+// (running max / running sum) softmax per wave.  Compared with the separate q.K^T and softmax.V passes this halves
+// the number of page visits (one TLB / DRAM-page walk per 2/3 of a block instead of per 1/3 -- pages are scattered
+// over the pool), removes the softmax launch and keeps the scores out of the critical path.
+//
+// The reference's contract for the composition (src/kernels/paged_attention.cu:358-377) is kept: on return
+// qkt_output holds the masked softmax probabilities with a zero tail, attention_result holds sum p.V, rows with
+// length 0 give zeros.  Raw scores are written by the scan kernel; the combine kernel merges the per-chunk
+// (max, sum, partial output) triples in chunk order and normalises the row.
+//
+//   scan    grid = (B, chunks) rows fast (XCD balance), 256 threads; a wave owns whole pages
+//   combine grid = B, 256 threads
+#include <type_traits>
+
+#include "device_common.hpp"
+
+namespace mli {
+
+constexpr int kFuThreads = 256;
+constexpr int kFuWaves = kFuThreads / kWave;
+
+int sv_chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip
+size_t stats_region_bytes_for(int B, int S);
+int nt_loads_enabled();
+
+typedef uint32_t fu_u32x4 __attribute__((ext_vector_type(4)));
+typedef const fu_u32x4 __attribute__((address_space(1)))* fu_gu4_ptr;
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ fu_u32x4 fu_ldg(const void* p) {
+    if (NT) return __builtin_nontemporal_load((fu_gu4_ptr)(p));
+    return *(fu_gu4_ptr)(p);
+}
+
+// one 16-byte lane load holds EPL elements
+struct ElemF32 {
+    static constexpr int EPL = 4;
+    static constexpr int kBytes = 4;
+    static __device__ __forceinline__ void unpack(const fu_u32x4& r, float (&f)[4]) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    }
+};
+struct ElemBF16 {
+    static constexpr int EPL = 8;
+    static constexpr int kBytes = 2;
+    static __device__ __forceinline__ void unpack(const fu_u32x4& r, float (&f)[8]) {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+};
+
+template <class E, int NJ, bool NT>
+__global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
+    const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
+    float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
+    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct) {
+    constexpr int EPL = E::EPL;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
+    float* red = reinterpret_cast<float*>(smem_raw + (size_t)(ct / kPage) * 8);            // [waves][NJ*64*EPL]
+    __shared__ float2 wave_ml[kFuWaves];
+
+    const int b = blockIdx.x;
+    const int c = blockIdx.y;
+    const int L = min(lengths[b], S);
+    const int s0 = c * ct;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    float* qkt_row = qkt + (int64_t)b * S;
+
+    if (s0 >= L) {
+        if (direct) {  // single-chunk problem: this workgroup owns the whole (empty) row
+            for (int i = threadIdx.x; i < S; i += kFuThreads) qkt_row[i] = 0.f;
+            for (int i = threadIdx.x; i < D; i += kFuThreads) out[(int64_t)b * D + i] = 0.f;
+        }
+        return;
+    }
+    const int s1 = min(s0 + ct, L);
+    const int ntok = s1 - s0;
+    const int npages = (ntok + kPage - 1) / kPage;
+    for (int i = threadIdx.x; i < npages; i += kFuThreads)
+        ptr_sh[i] = page_table[(int64_t)b * (S / kPage) + s0 / kPage + i];
+    __syncthreads();
+
+    const int Du = D / EPL;  // lane-units per row
+    const float scale = sqrtf((float)D);
+    const int64_t row_bytes = (int64_t)3 * D * E::kBytes;  // consecutive token slots of a page
+    const int64_t seg_bytes = (int64_t)D * E::kBytes;      // segment stride inside a slot: x | K | V
+
+    // q in registers (NJ * EPL floats per lane), zero beyond the row
+    float qr[NJ][EPL];
+    bool live[NJ];
+    unsigned voff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int u = lane + j * kWave;
+        live[j] = u < Du;
+        // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
+        // them, so the loads need no per-lane predication
+        voff[j] = live[j] ? (unsigned)u * 16u : 0x40000000u;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPL + e] : 0.f;
+    }
+
+    float run_m = -INFINITY, run_l = 0.f;
+    float acc[NJ][EPL];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[j][e] = 0.f;
+    // Rolling prefetch over row batches.  A page is 2 * NB batches of TBR rows (K batches, then V batches); batch
+    // `pos` of every page lives in register buffer pos % 4, and before batch `pos` is consumed batch pos + 3 -- of
+    // this page or of the wave's next page -- is issued, so three batches (24 KiB at bf16 D=512) stay in flight
+    // per wave across the butterfly reduction, the softmax update and the page boundary.
+    constexpr int TBR = NJ == 1 ? 8 : 4;
+    constexpr int NB = 16 / TBR;
+    constexpr int NPOS = 2 * NB;
+    constexpr int PD = 3;
+    fu_u32x4 buf[4][TBR][NJ];
+
+    // Loads go through a buffer descriptor built from the wave-uniform page pointer: the 128-bit descriptor and
+    // the per-row offset live in SGPRs, each lane contributes one 32-bit byte offset (no 64-bit per-load address
+    // VGPRs), and the hardware range check (one page block) backs up the indexing.
+    const int block_bytes = kPage * 3 * D * E::kBytes;
+    auto page_ptr = [&](int pi) {
+        return reinterpret_cast<const char*>(wave_uniform(reinterpret_cast<const float*>(ptr_sh[pi])));
+    };
+    auto issue = [&](auto POS, const char* pg) {
+        constexpr int pos = decltype(POS)::value;
+        constexpr int bi = pos % 4;
+        // re-assert uniformity at the point of use: `pg` went through selects on the wave index, which the compiler
+        // treats as divergent and would wrap every load in a waterfall loop
+        const char* upg = reinterpret_cast<const char*>(wave_uniform(reinterpret_cast<const float*>(pg)));
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(upg), 0, block_bytes, 0x00020000);
+        const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * (int)row_bytes;
+#pragma unroll
+        for (int t = 0; t < TBR; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * (int)row_bytes, NT ? 2 : 0);
+    };
+
+    const char* page = wave < npages ? page_ptr(wave) : nullptr;
+    if (page != nullptr) {
+        issue(std::integral_constant<int, 0>{}, page);
+        issue(std::integral_constant<int, 1>{}, page);
+        issue(std::integral_constant<int, 2>{}, page);
+    }
+    for (int pi = wave; pi < npages; pi += kFuWaves) {
+        const char* next = pi + kFuWaves < npages ? page_ptr(pi + kFuWaves) : nullptr;
+        const int nt = min(kPage, ntok - pi * kPage);  // live tokens in this page (>= 1)
+        float sacc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sacc[t] = 0.f;
+        float p_lane = 0.f;
+
+        static_for<NPOS>([&](auto POS) {
+            constexpr int pos = decltype(POS)::value;
+            constexpr int bi = pos % 4;
+            constexpr int tgt = pos + PD;
+            if constexpr (tgt < NPOS) {
+                issue(std::integral_constant<int, tgt>{}, page);
+            } else {
+                if (next != nullptr) issue(std::integral_constant<int, tgt - NPOS>{}, next);  // wave-uniform
+            }
+            if constexpr (pos < NB) {
+                // ---- K batch: partial scores of slots pos*TBR .. pos*TBR+TBR-1 ----
+#pragma unroll
+                for (int t = 0; t < TBR; ++t)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float kf[EPL];
+                        E::unpack(buf[bi][t][j], kf);
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) sacc[pos * TBR + t] = fmaf(qr[j][e], kf[e], sacc[pos * TBR + t]);
+                    }
+                if constexpr (pos == NB - 1) {
+                    // all 16 slots scored (slots >= nt hold allocated but meaningless data: masked here)
+                    const float tot = wave_reduce16(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15
+                    const int slot = (lane >> 2) & 15;
+                    const bool valid = slot < nt;
+                    const float score = tot / scale;
+                    if (valid && (lane & 3) == 0) qkt_row[s0 + pi * kPage + slot] = score;  // raw; normalised later
+                    // online softmax update
+                    const float pm = wave_max(valid ? score : -INFINITY);
+                    const float m_new = fmaxf(run_m, pm);
+                    const float alpha = run_m == -INFINITY ? 0.f : expf(run_m - m_new);
+                    p_lane = valid ? expf(score - m_new) : 0.f;
+                    run_l = run_l * alpha + wave_sum((lane & 3) == 0 ? p_lane : 0.f);
+                    run_m = m_new;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) acc[j][e] *= alpha;
+                }
+            } else {
+                // ---- V batch: acc += p . V over the live slots ----
+                constexpr int first = (pos - NB) * TBR;
+#pragma unroll
+                for (int t = 0; t < TBR; ++t) {
+                    // the slot's probability sits in lane 4 * slot: broadcast through an SGPR
+                    const float p = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p_lane), 4 * (first + t)));
+                    if (first + t < nt) {  // wave-uniform: never multiply unwritten page memory, even by zero
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            float vf[EPL];
+                            E::unpack(buf[bi][t][j], vf);
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e) acc[j][e] = fmaf(p, vf[e], acc[j][e]);
+                        }
+                    }
+                }
+            }
+        });
+        page = next;
+    }
+
+    // ---- merge the four waves (fixed order) ----
+    constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes
+    if (lane == 0) wave_ml[wave] = make_float2(run_m, run_l);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) red[wave * kRowF + (j * kWave + lane) * EPL + e] = acc[j][e];
+    __syncthreads();
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kFuWaves; ++w) m = fmaxf(m, wave_ml[w].x);
+    float wsc[kFuWaves];
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFuWaves; ++w) {
+        wsc[w] = wave_ml[w].x == -INFINITY ? 0.f : expf(wave_ml[w].x - m);
+        l += wave_ml[w].y * wsc[w];
+    }
+    float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * nchunk_max + c) * D;
+    const float norm = direct ? 1.f / l : 1.f;
+    for (int i = threadIdx.x; i < D; i += kFuThreads) {  // element i of the row lives at red[...][i] by construction
+        float r = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFuWaves; ++w) r += red[w * kRowF + i] * wsc[w];
+        o[i] = r * norm;
+    }
+    if (direct) {
+        // whole row handled by this workgroup: normalise the scores in place and write the zero tail
+        __syncthreads();  // raw scores written by other waves of this workgroup are visible after the barrier
+        const float inv_l = 1.f / l;
+        for (int i = threadIdx.x; i < S; i += kFuThreads) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
+    } else if (threadIdx.x == 0) {
+        ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
+    }
+}
+
+// grid = (B, kCombineParts).  Every part merges the row's chunk statistics (cheap, identical result), part 0 also
+// writes attention_result; each part turns its slice of the raw scores into probabilities (zero tail included).
+constexpr int kCombineParts = 4;
+
+__global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
+    const float2* __restrict__ ml, const float* __restrict__ partial, const int* __restrict__ lengths,
+    float* __restrict__ qkt, float* __restrict__ out, int S, int D, int ct, int ml_per_row, int nchunk_max) {
+    const int b = blockIdx.x;
+    const int part = blockIdx.y;
+    const int L = min(lengths[b], S);
+    const int nc = (L + ct - 1) / ct;
+    float* qkt_row = qkt + (int64_t)b * S;
+    const int per = ((S + kCombineParts - 1) / kCombineParts + 3) & ~3;
+    const int i0 = part * per, i1 = min(S, i0 + per);
+    if (nc == 0) {
+        for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = 0.f;
+        if (part == 0) for (int i = threadIdx.x; i < D; i += kFuThreads) out[(int64_t)b * D + i] = 0.f;
+        return;
+    }
+    const float2* row = ml + (int64_t)b * ml_per_row;
+    float m = -INFINITY;
+    for (int i = 0; i < nc; ++i) m = fmaxf(m, row[i].x);
+    float l = 0.f;
+    for (int i = 0; i < nc; ++i) l += row[i].y * expf(row[i].x - m);
+    const float inv_l = 1.f / l;
+    if (part == 0) {
+        const float* pr = partial + (int64_t)b * nchunk_max * D;
+        for (int d = threadIdx.x; d < D; d += kFuThreads) {
+            float r = 0.f;
+            for (int i = 0; i < nc; ++i) r += pr[(int64_t)i * D + d] * expf(row[i].x - m);
+            out[(int64_t)b * D + d] = r * inv_l;
+        }
+    }
+    for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
+}
+
+static int g_flash = 1;
+void set_flash_decode(int v) { g_flash = v != 0; }
+
+// returns 1 when the fused path ran, 0 when the caller should take the three-kernel path, < 0 / > 1 on error
+// phases: bit 0 = scan kernel, bit 1 = combine kernel (3 = the whole block; 1 / 2 let bench.py time them apart)
+template <class E>
+static int launch_fused_decode(const float* q, const void* const* page_table, const int* lengths, float* qkt,
+                               float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st,
+                               int phases = 3) {
+    const int Du = D / E::EPL;
+    const int nj = ceil_div_i(Du, kWave);
+    if (!g_flash || nj > 2 || D % E::EPL != 0 || S % kPage != 0) return 0;
+    const int ct = sv_chunk_tokens_for(B, S);
+    const int nchunk = ceil_div_i(S, ct);
+    const int direct = nchunk == 1;
+    const size_t stats_bytes = stats_region_bytes_for(B, S);
+    float2* ml = nullptr;
+    float* partial = nullptr;
+    if (!direct) {
+        if (ws == nullptr || ws_bytes < stats_bytes + (size_t)B * nchunk * D * sizeof(float)) return 0;
+        ml = reinterpret_cast<float2*>(ws);
+        partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + stats_bytes);
+    }
+    const int ml_per_row = ceil_div_i(S, 64);
+    const size_t smem = (size_t)(ct / kPage) * 8 + (size_t)kFuWaves * nj * kWave * E::EPL * sizeof(float);
+    dim3 grid(B, nchunk);
+    const bool nt = nt_loads_enabled();
+#define MLI_FU_LAUNCH(NJ, NT)                                                                                     \
+    hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT>), grid, dim3(kFuThreads), smem, st, q, page_table, lengths, \
+                       qkt, out, ml, partial, S, D, ct, ml_per_row, nchunk, direct)
+    if (phases & 1) {
+        if (nj == 1) { if (nt) MLI_FU_LAUNCH(1, true); else MLI_FU_LAUNCH(1, false); }
+        else { if (nt) MLI_FU_LAUNCH(2, true); else MLI_FU_LAUNCH(2, false); }
+    }
+#undef MLI_FU_LAUNCH
+    int rc = launch_status();
+    if (rc) return rc > 0 ? rc + 1 : rc;  // keep 1 free for "ran"
+    if (!direct && (phases & 2)) {
+        hipLaunchKernelGGL(fused_decode_combine_kernel, dim3(B, kCombineParts), dim3(kFuThreads), 0, st, ml, partial,
+                           lengths, qkt, out, S, D, ct, ml_per_row, nchunk);
+        rc = launch_status();
+        if (rc) return rc > 0 ? rc + 1 : rc;
+    }
+    return 1;
+}
+
+int launch_fused_decode_f32(const float* q, const float* const* page_table, const int* lengths, float* qkt, float* out,
+                            int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    return launch_fused_decode<ElemF32>(q, reinterpret_cast<const void* const*>(page_table), lengths, qkt, out, B, S, D,
+                                        ws, ws_bytes, st);
+}
+
+int launch_fused_decode_bf16(const float* q, const uint16_t* const* page_table, const int* lengths, float* qkt,
+                             float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    return launch_fused_decode<ElemBF16>(q, reinterpret_cast<const void* const*>(page_table), lengths, qkt, out, B, S, D,
+                                         ws, ws_bytes, st);
+}
+
+}  // namespace mli
+
+extern "C" int mli_decode_scan_paged(const float* q_output, const void* const* page_table, const int* lengths,
+                                     float* qkt_output, float* attention_result, int n_batch, int n_sequence,
+                                     int emb_dim, int elem_bf16, int phases, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (phases < 1 || phases > 3) return MLI_ERR_BAD_ARG;
+    hipStream_t st = mli::as_stream(stream);
+    const int r = elem_bf16 ? mli::launch_fused_decode<mli::ElemBF16>(q_output, page_table, lengths, qkt_output,
+                                                                      attention_result, n_batch, n_sequence, emb_dim,
+                                                                      workspace, workspace_bytes, st, phases)
+                            : mli::launch_fused_decode<mli::ElemF32>(q_output, page_table, lengths, qkt_output,
+                                                                     attention_result, n_batch, n_sequence, emb_dim,
+                                                                     workspace, workspace_bytes, st, phases);
+    if (r == 1) return 0;
+    if (r == 0) return MLI_ERR_BAD_ARG;  // shape not covered by the single-pass kernel (emb_dim too wide) or no workspace
+    return r < 0 ? r : r - 1;
+}
+
+namespace mli {
+
+}  // namespace mli

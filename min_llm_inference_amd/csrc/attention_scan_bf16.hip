@@ -78,34 +78,48 @@ __global__ __launch_bounds__(kBfThreads) void qkt_paged_bf16_kernel(
     const int nj = (D8 + kWave - 1) / kWave;
     const int64_t row_bytes = (int64_t)3 * D * 2;  // bytes between consecutive token slots
 
+    // Software pipeline over half pages (8 K rows = 8 x 1 KiB per load batch): the loads of the next half page
+    // are issued before the current one is consumed, so a wave always has 8-16 row loads in flight -- the
+    // butterfly reduction of a page no longer leaves the wave without outstanding HBM requests.
     float run_m = -INFINITY, run_l = 0.f;
-    for (int pi = wave; pi < npages; pi += kBfWaves) {
-        const uint16_t* krow = wave_uniform16(ptr_sh[pi]) + D;  // segment 1 of slot 0
-        float acc[16];
+    const int pages_w = npages > wave ? (npages - wave + kBfWaves - 1) / kBfWaves : 0;
+    const int n_steps = pages_w * nj;  // one step = (page of this wave, 64-lane column chunk j)
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    auto load_half = [&](u32x4_t (&buf)[8], int step, int half) {
+        const int pi = wave + (step / nj) * kBfWaves;
+        const int i8 = lane + (step % nj) * kWave;
+        const char* krow = reinterpret_cast<const char*>(wave_uniform16(ptr_sh[pi]) + D) + half * 8 * row_bytes;
+        const unsigned voff = (unsigned)i8 * 16u;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-        for (int j = 0; j < nj; ++j) {
-            const int i8 = lane + j * kWave;
-            if (i8 < D8) {
-                const float4 qa = q_sh[2 * i8], qb = q_sh[2 * i8 + 1];
-                const unsigned voff = (unsigned)i8 * 16u;
+        for (int t = 0; t < 8; ++t) buf[t] = i8 < D8 ? ldg_u4<NT>(byte_off(krow + t * row_bytes, voff)) : zero4;
+    };
+    u32x4_t buf_a[8], buf_b[8];
+    float acc[16];
+    if (n_steps > 0) load_half(buf_a, 0, 0);
+    for (int step = 0; step < n_steps; ++step) {
+        const int j = step % nj;
+        const int i8 = lane + j * kWave;
+        load_half(buf_b, step, 1);
+        if (j == 0) {
 #pragma unroll
-                for (int h = 0; h < 16 / TB; ++h) {
-                    u32x4_t kv[TB];
-#pragma unroll
-                    for (int t = 0; t < TB; ++t)
-                        kv[t] = ldg_u4<NT>(byte_off(reinterpret_cast<const char*>(krow) + (h * TB + t) * row_bytes, voff));
-#pragma unroll
-                    for (int t = 0; t < TB; ++t) acc[h * TB + t] = dot8(qa, qb, kv[t], acc[h * TB + t]);
-                }
-            }
+            for (int t = 0; t < 16; ++t) acc[t] = 0.f;
         }
-        const float tot = wave_reduce16(acc, lane);
-        const int s = s0 + pi * kPage + (lane >> 2);
-        const bool writer = (lane & 3) == 0 && s < L;
-        const float score = tot / scale;
-        if (writer) qkt[(int64_t)b * S + s] = score;
-        if (st.stats != nullptr) stats_accumulate(score, writer, run_m, run_l);
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        if (i8 < D8) { qa = q_sh[2 * i8]; qb = q_sh[2 * i8 + 1]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = dot8(qa, qb, buf_a[t], acc[t]);
+        if (step + 1 < n_steps) load_half(buf_a, step + 1, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[8 + t] = dot8(qa, qb, buf_b[t], acc[8 + t]);
+        if (j == nj - 1) {
+            const int pi = wave + (step / nj) * kBfWaves;
+            const float tot = wave_reduce16(acc, lane);
+            const int s = s0 + pi * kPage + (lane >> 2);
+            const bool writer = (lane & 3) == 0 && s < L;
+            const float score = tot / scale;
+            if (writer) qkt[(int64_t)b * S + s] = score;
+            if (st.stats != nullptr) stats_accumulate(score, writer, run_m, run_l);
+        }
     }
     if (st.stats != nullptr) {
         if (lane == 0) wave_stats[wave] = make_float2(run_m, run_l);

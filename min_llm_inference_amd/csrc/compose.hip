@@ -25,6 +25,11 @@ int launch_scores_softmax_v_naive(const float*, const float*, const float*, cons
                                   void*, size_t, hipStream_t);
 int launch_scores_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*, float*, float*, int, int, int,
                                        void*, size_t, hipStream_t);
+// single-pass fused scan (attention_fused.hip): 1 = ran, 0 = not applicable (caller falls back), else error + (rc > 0)
+int launch_fused_decode_f32(const float*, const float* const*, const int*, float*, float*, int, int, int, void*, size_t,
+                            hipStream_t);
+int launch_fused_decode_bf16(const float*, const uint16_t* const*, const int*, float*, float*, int, int, int, void*,
+                             size_t, hipStream_t);
 int launch_latest_paged_bf16(uint16_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*, float*, int,
                              int, int, hipStream_t);
 int launch_fill_paged_bf16(uint16_t* const*, const int*, const int*, const uint16_t*, const uint16_t*, int, int, int,
@@ -48,6 +53,10 @@ int mli_paged_attention_bf16(mli_bf16* const* page_table, const int* lengths, co
     if (rc) return rc;
     rc = mli::launch_latest_paged_bf16(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim, st);
     if (rc) return rc;
+    const int fused = mli::launch_fused_decode_bf16(q_output, page_table, lengths, qkt_output, attention_result, n_batch,
+                                                    n_sequence, emb_dim, workspace, workspace_bytes, st);
+    if (fused == 1) return 0;
+    if (fused != 0) return fused < 0 ? fused : fused - 1;
     return mli::launch_scores_softmax_v_paged_bf16(q_output, page_table, lengths, qkt_output, attention_result,
                                                    n_batch, n_sequence, emb_dim, workspace, workspace_bytes, st);
 }
@@ -78,6 +87,10 @@ int mli_paged_attention(float* const* page_table, const int* lengths, const floa
     if (rc) return rc;
     rc = mli::launch_latest_paged(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim, st);
     if (rc) return rc;
+    const int fused = mli::launch_fused_decode_f32(q_output, page_table, lengths, qkt_output, attention_result, n_batch,
+                                                   n_sequence, emb_dim, workspace, workspace_bytes, st);
+    if (fused == 1) return 0;
+    if (fused != 0) return fused < 0 ? fused : fused - 1;
     return mli::launch_scores_softmax_v_paged(q_output, page_table, lengths, qkt_output, attention_result, n_batch,
                                               n_sequence, emb_dim, workspace, workspace_bytes, st);
 }

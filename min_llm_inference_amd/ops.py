@@ -201,6 +201,16 @@ def launch_paged_attention_decoder_multi_rounds_bf16(batch_result, emb_table, em
            "mli_paged_decoder_multi_rounds_bf16")
 
 
+def decode_scan_paged(q_output, page_table, lengths, qkt_output, attention_result, elem_bf16, phases=3):
+    """Single-pass scores + masked softmax + softmax.V over the pages (mli_decode_scan_paged)."""
+    B, D = q_output.shape
+    S = qkt_output.shape[1]
+    ws, need = workspace_for(B, S, D, q_output.device)
+    _check(load_library().mli_decode_scan_paged(_p(q_output), _p(page_table), _p(lengths), _p(qkt_output),
+                                                _p(attention_result), B, S, D, int(elem_bf16), int(phases), _p(ws),
+                                                need, _stream()), "mli_decode_scan_paged")
+
+
 # ---- encoder / decoder ---------------------------------------------------------------------
 def launch_inference_optimized_encoder_kernel(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices,
                                               n_new_items):

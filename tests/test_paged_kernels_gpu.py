@@ -137,6 +137,33 @@ def test_paged_attention_composition(oracle, mli, dev, seed, B, S, D, zero_every
         assert_close(host(d["qkt_output"]), c["qkt_output"], what="qkt_output (probabilities)")
 
 
+@pytest.mark.parametrize("seed,B,S,D", [(31, 24, 256, 512), (32, 9, 1024, 256), (33, 3, 4096, 512), (34, 40, 64, 64)])
+def test_decode_scan_single_pass(oracle, mli, dev, seed, B, S, D):
+    """mli_decode_scan_paged (what the compositions run after the projection): scores + masked softmax + softmax.V in
+    one visit per page, checked against the oracle's three host functions (qkt_host -> softmax -> softmax_v_host)."""
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=4)
+    ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], d["qkt_output"], d["attention_result"], False)
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+    assert_close(host(d["qkt_output"]), c["qkt_output"], what="probabilities (zero tail included)")
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+    got = host(d["qkt_output"])
+    for b in range(B):
+        assert (got[b, c["lengths"][b]:] == 0).all()
+
+
+def test_decode_scan_rejects_wide_rows(mli, dev):
+    """emb_dim beyond two lane loads per row is served by the separate entry points, not silently mis-computed."""
+    import torch
+    from min_llm_inference_amd import MliError, ops
+    z = torch.zeros(2, 2048, device=dev)
+    with pytest.raises(MliError):
+        ops.decode_scan_paged(z, torch.zeros(2, 4, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.int32, device=dev),
+                              torch.zeros(2, 64, device=dev), z.clone(), False)
+
+
 def test_page_table_indexing_bit_exact(oracle, mli, dev):
     """Integer-valued data make every fp32 sum exact in any order, so any mismatch is an INDEXING error:
     wrong page, wrong slot, wrong segment or wrong column.  Edge lengths 0, 1, 15, 16, 17, S-1 included."""

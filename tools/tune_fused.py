@@ -1,0 +1,24 @@
+"""A/B the composition forms (flash_decode on/off, chunk sizes) in one process (dev tool)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from min_llm_inference_amd import load_library  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "c4"
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+dev = torch.device("cuda:0")
+wl = bench.Workload(name, dev, 123, headroom=8, dtype=dtype)
+lib = load_library()
+alg = wl.algorithmic_bytes(wl.lengths_host)
+print(f"workload {name} {dtype}: step attention bytes {alg['step']/1e9:.3f} GB")
+for rnd in range(3):
+    for flash in (1, 0):
+        for ct in (0, 128, 256, 512, 1024):
+            lib.mli_tune(b"flash_decode", flash)
+            lib.mli_tune(b"chunk_tokens", ct)
+            t = bench.time_kernel(wl.attention, 20)
+            print(f"round {rnd} flash {flash} ct {ct:5d}: attention {t*1e3:8.1f} us  {alg['step']/t/1e6:7.0f} GB/s", flush=True)
