@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--mode", choices=["step", "engine"], default="step",
                     help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
     ap.add_argument("--engine-kind", choices=["paged", "paged_gemm"], default="paged_gemm")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--reference-quirk", action="store_true",
                     help="engine mode: reproduce the reference's stale-length upload (DESIGN.md deviation 2)")
     args = ap.parse_args()
@@ -325,12 +327,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend == "nccl":
+        raise SystemExit(f"rank {local_rank} has no GPU ({n_dev} visible): one rank per GPU")
+    dev = torch.device("cuda", local_rank % max(n_dev, 1))  # ranks share a GPU only in gloo rehearsals
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     if args.mode == "engine":
         if world > 1:
@@ -450,8 +458,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # ranks leave together (rank 0 may still have been in its roofline pass)
         dist.destroy_process_group()
 
 
