@@ -135,10 +135,13 @@ class Workload:
         self.decoder()
 
     # ---- the individual kernels, for the roofline pass ------------------------------------
-    def kernels(self):
+    def kernels_separate(self):
+        return self.kernels(fused_scan=False)
+
+    def kernels(self, fused_scan=True):
         w = self
         bf = self.dtype == "bf16"
-        if self.layout == "paged" and self.D * (2 if bf else 4) <= 2048:
+        if fused_scan and self.layout == "paged" and self.D * (2 if bf else 4) <= 2048:
             # the composition runs the single-pass scan (mli_decode_scan_paged): time its two launches apart
             latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
             return {

@@ -60,8 +60,10 @@ struct ElemBF16 {
     }
 };
 
-template <class E, int NJ, bool NT>
-__global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
+// TBR = rows per load batch, MINW = waves per SIMD the register allocator must leave room for
+// WAVES = waves per workgroup (each wave owns whole pages; 1 = every wave is its own scheduling unit)
+template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
     int S, int D, int ct, int ml_per_row, int nchunk_max, int direct) {
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
     float* red = reinterpret_cast<float*>(smem_raw + (size_t)(ct / kPage) * 8);            // [waves][NJ*64*EPL]
-    __shared__ float2 wave_ml[kFuWaves];
+    __shared__ float2 wave_ml[WAVES];
 
     const int b = blockIdx.x;
     const int c = blockIdx.y;
@@ -81,15 +83,15 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
 
     if (s0 >= L) {
         if (direct) {  // single-chunk problem: this workgroup owns the whole (empty) row
-            for (int i = threadIdx.x; i < S; i += kFuThreads) qkt_row[i] = 0.f;
-            for (int i = threadIdx.x; i < D; i += kFuThreads) out[(int64_t)b * D + i] = 0.f;
+            for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = 0.f;
+            for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) out[(int64_t)b * D + i] = 0.f;
         }
         return;
     }
     const int s1 = min(s0 + ct, L);
     const int ntok = s1 - s0;
     const int npages = (ntok + kPage - 1) / kPage;
-    for (int i = threadIdx.x; i < npages; i += kFuThreads)
+    for (int i = threadIdx.x; i < npages; i += (WAVES * kWave))
         ptr_sh[i] = page_table[(int64_t)b * (S / kPage) + s0 / kPage + i];
     __syncthreads();
 
@@ -123,7 +125,6 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
     // `pos` of every page lives in register buffer pos % 4, and before batch `pos` is consumed batch pos + 3 -- of
     // this page or of the wave's next page -- is issued, so three batches (24 KiB at bf16 D=512) stay in flight
     // per wave across the butterfly reduction, the softmax update and the page boundary.
-    constexpr int TBR = NJ == 1 ? 8 : 4;
     constexpr int NB = 16 / TBR;
     constexpr int NPOS = 2 * NB;
     constexpr int PD = 3;
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
         issue(std::integral_constant<int, 1>{}, page);
         issue(std::integral_constant<int, 2>{}, page);
     }
-    for (int pi = wave; pi < npages; pi += kFuWaves) {
-        const char* next = pi + kFuWaves < npages ? page_ptr(pi + kFuWaves) : nullptr;
+    for (int pi = wave; pi < npages; pi += WAVES) {
+        const char* next = pi + WAVES < npages ? page_ptr(pi + WAVES) : nullptr;
         const int nt = min(kPage, ntok - pi * kPage);  // live tokens in this page (>= 1)
         float sacc[16];
 #pragma unroll
@@ -237,27 +238,27 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_scan_kernel(
     __syncthreads();
     float m = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < kFuWaves; ++w) m = fmaxf(m, wave_ml[w].x);
-    float wsc[kFuWaves];
+    for (int w = 0; w < WAVES; ++w) m = fmaxf(m, wave_ml[w].x);
+    float wsc[WAVES];
     float l = 0.f;
 #pragma unroll
-    for (int w = 0; w < kFuWaves; ++w) {
+    for (int w = 0; w < WAVES; ++w) {
         wsc[w] = wave_ml[w].x == -INFINITY ? 0.f : expf(wave_ml[w].x - m);
         l += wave_ml[w].y * wsc[w];
     }
     float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * nchunk_max + c) * D;
     const float norm = direct ? 1.f / l : 1.f;
-    for (int i = threadIdx.x; i < D; i += kFuThreads) {  // element i of the row lives at red[...][i] by construction
+    for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) {  // element i of the row lives at red[...][i] by construction
         float r = 0.f;
 #pragma unroll
-        for (int w = 0; w < kFuWaves; ++w) r += red[w * kRowF + i] * wsc[w];
+        for (int w = 0; w < WAVES; ++w) r += red[w * kRowF + i] * wsc[w];
         o[i] = r * norm;
     }
     if (direct) {
         // whole row handled by this workgroup: normalise the scores in place and write the zero tail
         __syncthreads();  // raw scores written by other waves of this workgroup are visible after the barrier
         const float inv_l = 1.f / l;
-        for (int i = threadIdx.x; i < S; i += kFuThreads) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
+        for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
     } else if (threadIdx.x == 0) {
         ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
     }
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
 }
 
 static int g_flash = 1;
+static int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
 void set_flash_decode(int v) { g_flash = v != 0; }
+void set_flash_variant(int v) { g_flash_variant = v; }
 
 // returns 1 when the fused path ran, 0 when the caller should take the three-kernel path, < 0 / > 1 on error
 // phases: bit 0 = scan kernel, bit 1 = combine kernel (3 = the whole block; 1 / 2 let bench.py time them apart)
@@ -311,7 +314,10 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
     if (!g_flash || nj > 2 || D % E::EPL != 0 || S % kPage != 0) return 0;
-    const int ct = sv_chunk_tokens_for(B, S);
+    // variant 3: single-wave workgroups of 128 tokens -- every wave is its own scheduling unit, no LDS merge,
+    // no barrier; the hardware dispatcher does the load balancing
+    const bool solo = g_flash_variant == 3 && S > 128;
+    const int ct = solo ? 128 : sv_chunk_tokens_for(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     const size_t stats_bytes = stats_region_bytes_for(B, S);
@@ -323,15 +329,25 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + stats_bytes);
     }
     const int ml_per_row = ceil_div_i(S, 64);
-    const size_t smem = (size_t)(ct / kPage) * 8 + (size_t)kFuWaves * nj * kWave * E::EPL * sizeof(float);
+    const int waves = solo ? 1 : kFuWaves;
+    const size_t smem = (size_t)(ct / kPage) * 8 + (size_t)waves * nj * kWave * E::EPL * sizeof(float);
     dim3 grid(B, nchunk);
     const bool nt = nt_loads_enabled();
-#define MLI_FU_LAUNCH(NJ, NT)                                                                                     \
-    hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT>), grid, dim3(kFuThreads), smem, st, q, page_table, lengths, \
-                       qkt, out, ml, partial, S, D, ct, ml_per_row, nchunk, direct)
+#define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES)                                                                   \
+    hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES>), grid, dim3(WAVES * kWave), smem, st, q, \
+                       page_table, lengths, qkt, out, ml, partial, S, D, ct, ml_per_row, nchunk, direct)
     if (phases & 1) {
-        if (nj == 1) { if (nt) MLI_FU_LAUNCH(1, true); else MLI_FU_LAUNCH(1, false); }
-        else { if (nt) MLI_FU_LAUNCH(2, true); else MLI_FU_LAUNCH(2, false); }
+        if (nj == 1) {
+            if (!nt) MLI_FU_LAUNCH(1, false, 8, 2, 4);
+            else if (solo) MLI_FU_LAUNCH(1, true, 8, 2, 1);
+            else if (g_flash_variant == 2) MLI_FU_LAUNCH(1, true, 4, 4, 4);
+            else MLI_FU_LAUNCH(1, true, 8, 2, 4);
+        } else {
+            if (!nt) MLI_FU_LAUNCH(2, false, 4, 2, 4);
+            else if (solo) MLI_FU_LAUNCH(2, true, 4, 2, 1);
+            else if (g_flash_variant == 2) MLI_FU_LAUNCH(2, true, 2, 4, 4);
+            else MLI_FU_LAUNCH(2, true, 4, 2, 4);
+        }
     }
 #undef MLI_FU_LAUNCH
     int rc = launch_status();

@@ -68,6 +68,51 @@ __global__ __launch_bounds__(256) void read_regions(const float4* __restrict__ s
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// page-shaped access: 16 rows per block, blocks visited through a permutation (scattered pages); UNROLL rows of
+// one block in flight per wave; reads `row_f4` float4 at `col_f4` of every row (K only, or K|V)
+template <int UNROLL, bool NT, int EXTRA = 0>
+__global__ __launch_bounds__(256) void read_blocks(const float4* __restrict__ src, float* __restrict__ sink,
+                                                    const int* __restrict__ perm, int nblocks, int row_f4, int col_f4,
+                                                    long stride_f4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.f;
+    const int per_row = (row_f4 + 63) / 64;
+    for (long bi = wave; bi < nblocks; bi += nwaves) {
+        const long base = (long)perm[bi] * 16 * stride_f4 + col_f4;
+        for (int r0 = 0; r0 < 16; r0 += UNROLL) {
+            for (int j = 0; j < per_row; ++j) {
+                f4v v[UNROLL];
+                const int i = lane + j * 64;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const f4v z = {0, 0, 0, 0};
+                    if (i < row_f4) {
+                        const f4v __attribute__((address_space(1)))* p = (const f4v __attribute__((address_space(1)))*)(src + base + (long)(r0 + u) * stride_f4 + i);
+                        v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+                    } else {
+                        v[u] = z;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    acc += v[u].x + v[u].y + v[u].z + v[u].w;
+                    // EXTRA independent-ish VALU ops per 16-byte load (4 accumulators), to mimic a kernel's arithmetic
+                    float a0 = v[u].x, a1 = v[u].y, a2 = v[u].z, a3 = v[u].w;
+#pragma unroll
+                    for (int k = 0; k < EXTRA / 4; ++k) {
+                        a0 = fmaf(a0, 1.0001f, a1); a1 = fmaf(a1, 0.9999f, a2); a2 = fmaf(a2, 1.0002f, a3); a3 = fmaf(a3, 0.9998f, a0);
+                    }
+                    acc += a0 + a1 + a2 + a3;
+                }
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 template <int UNROLL>
 __global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x);
@@ -137,6 +182,38 @@ int main() {
             float nt16 = time_ms([&] { hipLaunchKernelGGL((read_rows<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
             double bytes = (double)rows * sh.row_f4 * 16;
             printf("read %-44s grid %5d: u4 %.0f  u8 %.0f  u16 %.0f | nt u8 %.0f  nt u16 %.0f GB/s\n", sh.name, grid, bytes / ms4 / 1e6, bytes / ms8 / 1e6, bytes / ms16 / 1e6, bytes / nt8 / 1e6, bytes / nt16 / 1e6);
+        }
+    }
+    {   // scattered page blocks: 16 token slots per block, slot = stride_f4 float4 (x | K | V)
+        struct PShape { const char* name; int row_f4, col_f4; long stride_f4; };
+        PShape ps[] = {{"bf16 D=512: K only   (1 KiB of every 3 KiB, 48 KiB blocks)", 64, 64, 192},
+                       {"bf16 D=512: K|V      (2 KiB of every 3 KiB, 48 KiB blocks)", 128, 64, 192},
+                       {"fp32 D=512: K|V      (4 KiB of every 6 KiB, 96 KiB blocks)", 256, 128, 384}};
+        for (auto& sh : ps) {
+            const int nblocks = (int)(n4 / (16 * sh.stride_f4));  // every block lies inside the 4 GiB buffer
+            std::vector<int> lin(nblocks), shuf(nblocks);
+            for (int i = 0; i < nblocks; ++i) lin[i] = shuf[i] = i;
+            unsigned long long seed = 88172645463325252ULL;
+            for (int i = nblocks - 1; i > 0; --i) {  // Fisher-Yates with xorshift
+                seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+                int j = (int)(seed % (unsigned long long)(i + 1));
+                int t = shuf[i]; shuf[i] = shuf[j]; shuf[j] = t;
+            }
+            int* dperm;
+            CK(hipMalloc(&dperm, sizeof(int) * nblocks));
+            double bytes = (double)nblocks * 16 * sh.row_f4 * 16;
+            for (int mode = 0; mode < 2; ++mode) {
+                CK(hipMemcpy(dperm, mode ? shuf.data() : lin.data(), sizeof(int) * nblocks, hipMemcpyHostToDevice));
+                for (int grid : {2048, 8192}) {
+                    float a = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float b = time_ms([&] { hipLaunchKernelGGL((read_blocks<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c8 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 8>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c16 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 16>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c32 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 32>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    printf("blocks %-62s %s grid %5d: nt u8 %.0f  nt u16 %.0f | u8 + 8/16/32 VALU per load: %.0f %.0f %.0f GB/s\n", sh.name, mode ? "shuffled" : "linear  ", grid, bytes / a / 1e6, bytes / b / 1e6, bytes / c8 / 1e6, bytes / c16 / 1e6, bytes / c32 / 1e6);
+                }
+            }
+            CK(hipFree(dperm));
         }
     }
     return 0;

@@ -15,10 +15,11 @@ wl = bench.Workload(name, dev, 123, headroom=8, dtype=dtype)
 lib = load_library()
 alg = wl.algorithmic_bytes(wl.lengths_host)
 print(f"workload {name} {dtype}: step attention bytes {alg['step']/1e9:.3f} GB")
+scan = [v for k, v in wl.kernels().items() if k.startswith("fused_decode_scan")][0]
 for rnd in range(3):
-    for flash in (1, 0):
-        for ct in (0, 128, 256, 512, 1024):
-            lib.mli_tune(b"flash_decode", flash)
+    for variant in (0, 3):
+        for ct in (0,):
+            lib.mli_tune(b"flash_variant", variant)
             lib.mli_tune(b"chunk_tokens", ct)
-            t = bench.time_kernel(wl.attention, 20)
-            print(f"round {rnd} flash {flash} ct {ct:5d}: attention {t*1e3:8.1f} us  {alg['step']/t/1e6:7.0f} GB/s", flush=True)
+            t = bench.time_kernel(scan, 20)
+            print(f"round {rnd} variant {variant} ct {ct:5d}: scan {t*1e3:8.1f} us  {alg['scan']/t/1e6:7.0f} GB/s", flush=True)
