@@ -34,6 +34,8 @@ WORKLOADS = {
     "c2": ("naive", 256, 256, 1024),
     "c3": ("paged", 256, 256, 1024),
     "c4": ("paged", 1024, 512, 4096),
+    # the reference's own profiling shape (tests/paged_for_profile.cpp:11-23) as a fixed-state decode step
+    "e1": ("paged", 1024, 2048, 128),
 }
 N_VOCAB = 1024
 
@@ -141,7 +143,7 @@ class Workload:
     def kernels(self, fused_scan=True):
         w = self
         bf = self.dtype == "bf16"
-        if fused_scan and self.layout == "paged" and self.D * (2 if bf else 4) <= 2048:
+        if fused_scan and self.layout == "paged" and self.D <= 2048:
             # the composition runs the single-pass scan (mli_decode_scan_paged): time its two launches apart
             latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
             return {
@@ -219,34 +221,49 @@ def cpu_baseline(wl, budget_s=12.0):
     """The CPU oracle (single-threaded port of the reference's host functions) on a bounded row sample of the
     same workload, contiguous layout (the reference has no CPU paged path), decode step only (n_new = 0)."""
     import oracle
+    from concurrent.futures import ThreadPoolExecutor
     D, S = wl.D, wl.S
     rng = np.random.default_rng(1)
-
-    def run(n):
-        L = wl.lengths_host[:n].copy()
-        inp = rng.random((n, S, D), dtype=np.float32)
-        kt = rng.random((n, D, S), dtype=np.float32)
-        v = rng.random((n, S, D), dtype=np.float32)
-        w = [((rng.random((D, D), dtype=np.float32) * 2 - 1) / np.sqrt(D)).astype(np.float32) for _ in range(3)]
-        q = np.zeros((n, D), np.float32)
-        s = np.zeros((n, S), np.float32)
-        o = np.zeros((n, D), np.float32)
-        idx = np.zeros((n,), np.int32)
-        t0 = time.perf_counter()
-        oracle.self_attention_inference_host(inp, L, w[0], w[1], w[2], idx, kt, v, q, s, o, 0)
-        return time.perf_counter() - t0, int((L > 0).sum())
-
     n = int(min(wl.B, 4e9 // (3 * S * D * 4)))  # row sample bounded by ~4 GB of host memory
-    total_t, total_tok, reps = 0.0, 0, 0
+    L = wl.lengths_host[:n].copy()
+    inp = rng.random((n, S, D), dtype=np.float32)
+    kt = rng.random((n, D, S), dtype=np.float32)
+    v = rng.random((n, S, D), dtype=np.float32)
+    w = [((rng.random((D, D), dtype=np.float32) * 2 - 1) / np.sqrt(D)).astype(np.float32) for _ in range(3)]
+    q = np.zeros((n, D), np.float32)
+    s = np.zeros((n, S), np.float32)
+    o = np.zeros((n, D), np.float32)
+    idx = np.zeros((n,), np.int32)
+    live = int((L > 0).sum())
+
+    def rows(lo, hi):  # one decode step over rows [lo, hi): contiguous row slices are contiguous arrays
+        oracle.self_attention_inference_host(inp[lo:hi], L[lo:hi], w[0], w[1], w[2], idx[lo:hi], kt[lo:hi], v[lo:hi],
+                                             q[lo:hi], s[lo:hi], o[lo:hi], 0)
+
+    total_t, reps = 0.0, 0
     while total_t < budget_s and reps < 50:      # repeat the decode step over the sample until ~budget_s of CPU work
-        t, live = run(n)
-        total_t += t
-        total_tok += live
+        t0 = time.perf_counter()
+        rows(0, n)
+        total_t += time.perf_counter() - t0
         reps += 1
-    return {"value": total_tok / total_t, "unit": "tokens/s", "cores": 1, "kind": "port",
+    # the same step with the rows dealt to every host core (the reference's CPU path is single-threaded; rows are
+    # independent, so this is the obvious parallel form of it -- SURVEY 8(d)(ii)); ctypes calls release the GIL
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = max(1, min(cores, n))
+    cuts = [n * i // nthr for i in range(nthr + 1)]
+    mt_t, mt_reps = 0.0, 0
+    with ThreadPoolExecutor(nthr) as pool:
+        while mt_t < budget_s / 2 and mt_reps < 200:
+            t0 = time.perf_counter()
+            list(pool.map(lambda i: rows(cuts[i], cuts[i + 1]), range(nthr)))
+            mt_t += time.perf_counter() - t0
+            mt_reps += 1
+    return {"value": live * reps / total_t, "unit": "tokens/s", "cores": 1, "kind": "port",
             "sample": f"{reps} decode steps over {n} of {wl.B} rows of the same workload shape (contiguous layout, "
                       f"n_new=0, fp32 -- the reference's CPU path has no paged or bf16 form), {total_t:.1f} s "
-                      f"single-threaded oracle_cpu.c"}
+                      f"single-threaded oracle_cpu.c",
+            "all_cores": {"value": live * mt_reps / mt_t, "unit": "tokens/s", "cores": nthr,
+                          "sample": f"{mt_reps} steps over the same rows split across {nthr} threads, {mt_t:.1f} s"}}
 
 
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md

@@ -62,7 +62,12 @@ struct ElemBF16 {
 
 // TBR = rows per load batch, MINW = waves per SIMD the register allocator must leave room for
 // WAVES = waves per workgroup (each wave owns whole pages; 1 = every wave is its own scheduling unit)
-template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES>
+// DS = false: a wave owns whole pages (rows of up to NJ * 64 lane loads) and the waves are merged at the end;
+// DS = true ("D-split", wide rows): every wave visits every page of the chunk but owns a slice of NJ * 64 lane loads
+//      of each row; the 16 partial scores of a page are exchanged through LDS (one barrier per page, double
+//      buffered), after which all waves hold identical softmax state and accumulate their own slice of the output
+//      -- perfect balance between the waves however few pages a row has, and no end-of-kernel merge.
+template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false>
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     unsigned voff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int u = lane + j * kWave;
+        const int u = (DS ? wave * NJ * kWave : 0) + lane + j * kWave;
         live[j] = u < Du;
         // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
         // them, so the loads need no per-lane predication
@@ -153,14 +158,16 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
                 buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * (int)row_bytes, NT ? 2 : 0);
     };
 
-    const char* page = wave < npages ? page_ptr(wave) : nullptr;
+    constexpr int PSTEP = DS ? 1 : WAVES;
+    const int p_first = DS ? 0 : wave;
+    const char* page = p_first < npages ? page_ptr(p_first) : nullptr;
     if (page != nullptr) {
         issue(std::integral_constant<int, 0>{}, page);
         issue(std::integral_constant<int, 1>{}, page);
         issue(std::integral_constant<int, 2>{}, page);
     }
-    for (int pi = wave; pi < npages; pi += WAVES) {
-        const char* next = pi + WAVES < npages ? page_ptr(pi + WAVES) : nullptr;
+    for (int pi = p_first; pi < npages; pi += PSTEP) {
+        const char* next = pi + PSTEP < npages ? page_ptr(pi + PSTEP) : nullptr;
         const int nt = min(kPage, ntok - pi * kPage);  // live tokens in this page (>= 1)
         float sacc[16];
 #pragma unroll
@@ -189,11 +196,21 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
                     }
                 if constexpr (pos == NB - 1) {
                     // all 16 slots scored (slots >= nt hold allocated but meaningless data: masked here)
-                    const float tot = wave_reduce16(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15
+                    float tot = wave_reduce16(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15
                     const int slot = (lane >> 2) & 15;
+                    if constexpr (DS) {
+                        // complete the dot products across the waves' row slices (fixed order: identical in every wave)
+                        float* xs = red + (pi & 1) * (WAVES * 16);
+                        if ((lane & 3) == 0) xs[wave * 16 + slot] = tot;
+                        __syncthreads();
+                        tot = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WAVES; ++w) tot += xs[w * 16 + slot];
+                    }
                     const bool valid = slot < nt;
                     const float score = tot / scale;
-                    if (valid && (lane & 3) == 0) qkt_row[s0 + pi * kPage + slot] = score;  // raw; normalised later
+                    if (valid && (lane & 3) == 0 && (!DS || wave == 0))
+                        qkt_row[s0 + pi * kPage + slot] = score;  // raw; normalised later
                     // online softmax update
                     const float pm = wave_max(valid ? score : -INFINITY);
                     const float m_new = fmaxf(run_m, pm);
@@ -228,6 +245,29 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
         page = next;
     }
 
+    if constexpr (DS) {
+        // every wave holds the chunk's (max, sum) and its own slice of the output
+        float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * nchunk_max + c) * D;
+        const float norm = direct ? 1.f / run_l : 1.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (!live[j]) continue;
+            const int u = wave * NJ * kWave + lane + j * kWave;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4)
+                *reinterpret_cast<float4*>(o + (int64_t)u * EPL + e) =
+                    make_float4(acc[j][e] * norm, acc[j][e + 1] * norm, acc[j][e + 2] * norm, acc[j][e + 3] * norm);
+        }
+        if (direct) {
+            __syncthreads();  // wave 0's raw scores are visible to the workgroup after the barrier
+            const float inv_l = 1.f / run_l;
+            for (int i = threadIdx.x; i < S; i += (WAVES * kWave))
+                qkt_row[i] = i < L ? expf(qkt_row[i] - run_m) * inv_l : 0.f;
+        } else if (threadIdx.x == 0) {
+            ml[(int64_t)b * ml_per_row + c] = make_float2(run_m, run_l);
+        }
+        return;
+    }
     // ---- merge the four waves (fixed order) ----
     constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes
     if (lane == 0) wave_ml[wave] = make_float2(run_m, run_l);
@@ -313,10 +353,12 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
                                int phases = 3) {
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
-    if (!g_flash || nj > 2 || D % E::EPL != 0 || S % kPage != 0) return 0;
+    if (!g_flash || nj > 8 || D % E::EPL != 0 || S % kPage != 0) return 0;
+    const bool dsplit = nj > 2;  // wide rows: the four waves split the row instead of the pages
+    const int nj_ds = ceil_div_i(Du, kWave * kFuWaves);  // 1 or 2
     // variant 3: single-wave workgroups of 128 tokens -- every wave is its own scheduling unit, no LDS merge,
     // no barrier; the hardware dispatcher does the load balancing
-    const bool solo = g_flash_variant == 3 && S > 128;
+    const bool solo = g_flash_variant == 3 && S > 128 && !dsplit;
     const int ct = solo ? 128 : sv_chunk_tokens_for(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
@@ -330,14 +372,24 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     }
     const int ml_per_row = ceil_div_i(S, 64);
     const int waves = solo ? 1 : kFuWaves;
-    const size_t smem = (size_t)(ct / kPage) * 8 + (size_t)waves * nj * kWave * E::EPL * sizeof(float);
+    const size_t smem = (size_t)(ct / kPage) * 8 +
+                        (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
     dim3 grid(B, nchunk);
     const bool nt = nt_loads_enabled();
-#define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES)                                                                   \
-    hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES>), grid, dim3(WAVES * kWave), smem, st, q, \
-                       page_table, lengths, qkt, out, ml, partial, S, D, ct, ml_per_row, nchunk, direct)
+#define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES, ...)                                                              \
+    hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
+                       dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \
+                       ml_per_row, nchunk, direct)
     if (phases & 1) {
-        if (nj == 1) {
+        if (dsplit) {
+            if (nj_ds == 1) {
+                if (nt) MLI_FU_LAUNCH(1, true, 8, 2, 4, true);
+                else MLI_FU_LAUNCH(1, false, 8, 2, 4, true);
+            } else {
+                if (nt) MLI_FU_LAUNCH(2, true, 4, 2, 4, true);
+                else MLI_FU_LAUNCH(2, false, 4, 2, 4, true);
+            }
+        } else if (nj == 1) {
             if (!nt) MLI_FU_LAUNCH(1, false, 8, 2, 4);
             else if (solo) MLI_FU_LAUNCH(1, true, 8, 2, 1);
             else if (g_flash_variant == 2) MLI_FU_LAUNCH(1, true, 4, 4, 4);

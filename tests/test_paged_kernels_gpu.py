@@ -137,7 +137,8 @@ def test_paged_attention_composition(oracle, mli, dev, seed, B, S, D, zero_every
         assert_close(host(d["qkt_output"]), c["qkt_output"], what="qkt_output (probabilities)")
 
 
-@pytest.mark.parametrize("seed,B,S,D", [(31, 24, 256, 512), (32, 9, 1024, 256), (33, 3, 4096, 512), (34, 40, 64, 64)])
+@pytest.mark.parametrize("seed,B,S,D", [(31, 24, 256, 512), (32, 9, 1024, 256), (33, 3, 4096, 512), (34, 40, 64, 64),
+                                        (35, 12, 128, 2048), (36, 7, 1024, 1024), (37, 5, 4096, 1540)])
 def test_decode_scan_single_pass(oracle, mli, dev, seed, B, S, D):
     """mli_decode_scan_paged (what the compositions run after the projection): scores + masked softmax + softmax.V in
     one visit per page, checked against the oracle's three host functions (qkt_host -> softmax -> softmax_v_host)."""
@@ -155,10 +156,11 @@ def test_decode_scan_single_pass(oracle, mli, dev, seed, B, S, D):
 
 
 def test_decode_scan_rejects_wide_rows(mli, dev):
-    """emb_dim beyond two lane loads per row is served by the separate entry points, not silently mis-computed."""
+    """emb_dim beyond 2048 (eight 16-byte lane loads per fp32 row) is served by the separate entry points, not silently
+    mis-computed."""
     import torch
     from min_llm_inference_amd import MliError, ops
-    z = torch.zeros(2, 2048, device=dev)
+    z = torch.zeros(2, 4096, device=dev)
     with pytest.raises(MliError):
         ops.decode_scan_paged(z, torch.zeros(2, 4, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.int32, device=dev),
                               torch.zeros(2, 64, device=dev), z.clone(), False)
