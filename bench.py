@@ -249,7 +249,7 @@ def cpu_baseline(wl, budget_s=12.0):
     # the same step with the rows dealt to every host core (the reference's CPU path is single-threaded; rows are
     # independent, so this is the obvious parallel form of it -- SURVEY 8(d)(ii)); ctypes calls release the GIL
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    nthr = max(1, min(cores, n))
+    nthr = max(1, min(cores, n, int(os.environ.get("MLI_CPU_THREADS", "16"))))  # a one-GPU box's CPU share is 16
     cuts = [n * i // nthr for i in range(nthr + 1)]
     mt_t, mt_reps = 0.0, 0
     with ThreadPoolExecutor(nthr) as pool:
@@ -301,7 +301,8 @@ def run_engine_mode(args, rank, world, dev):
     figure README.md:54-82 quotes (123 284 tok/s on an unnamed NVIDIA GPU).  Each rank runs an independent
     replica of the workload on its own GPU."""
     from min_llm_inference_amd import engine as eng
-    B, S, D, V = 1024, 128, 2048, 1024
+    _, B, D, S = WORKLOADS[args.workload if args.workload != "c4" or args.engine_shape else "e1"]
+    V = N_VOCAB
     rng = np.random.default_rng(0x5EED0100 + rank)
 
     def u(*shape, scale=1.0):
@@ -309,15 +310,18 @@ def run_engine_mode(args, rank, world, dev):
 
     emb = u(V, D)
     emb[ops.EOF_TOKEN_ID] *= 1.0001  # the reference scales the EOF row the same way
-    kind = {"paged": eng.PAGED, "paged_gemm": eng.PAGED_GEMM}[args.engine_kind]
+    kind = {"paged": eng.PAGED, "paged_gemm": eng.PAGED_GEMM, "paged_bf16": eng.PAGED_BF16}[args.engine_kind]
+    # page pool: the reference gives 4 pages per slot at S = 128, i.e. half of the worst case B * S / 16 -- rows
+    # outgrow it, so page growth and preemption are part of the measured run (mode E)
+    n_blocks = B * S // 32
     e = eng.Engine(kind, B, S, D, V, emb, u(S, D), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)),
-                   u(D, D, scale=1 / np.sqrt(D)), n_blocks=4 * B, n_forward_rounds=1, device=dev.index,
+                   u(D, D, scale=1 / np.sqrt(D)), n_blocks=n_blocks, n_forward_rounds=1, device=dev.index,
                    reference_length_reset_quirk=args.reference_quirk)
     for i in range(2 * B):
         e.add_item(i, rng.integers(0, ops.EOF_TOKEN_ID, size=int(rng.integers(1, 65))))
     st = e.run()
     assert st.finished == 2 * B
-    return st
+    return st, (B, S, D, V, n_blocks)
 
 
 def main():
@@ -333,7 +337,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", choices=["step", "engine"], default="step",
                     help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
-    ap.add_argument("--engine-kind", choices=["paged", "paged_gemm"], default="paged_gemm")
+    ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16"], default="paged_gemm",
+                    help="paged_bf16 = extension: bf16 pages and weights (BASELINE config 4 dtype)")
+    ap.add_argument("--engine-shape", action="store_true",
+                    help="engine mode: run the --workload shape (e.g. c4) instead of the reference's profiling shape e1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--reference-quirk", action="store_true",
@@ -363,7 +370,8 @@ def main():
     if args.mode == "engine":
         if world > 1:
             dist.barrier()
-        st = run_engine_mode(args, rank, world, dev)
+        st, (eB, eS, eD, eV, e_blocks) = run_engine_mode(args, rank, world, dev)
+        ref_shape = (eB, eS, eD) == (1024, 128, 2048)
         tok = torch.tensor([float(st.total_tokens)], device=dev)
         sec = torch.tensor([st.seconds], device=dev)
         if world > 1:
@@ -374,11 +382,15 @@ def main():
                 "metric": "decode tokens/sec (whole node) on synthetic batch", "value": tok.item() / sec.item(),
                 "unit": "tokens/s", "n_gpus": world, "steps": int(st.iterations), "warmup": 0,
                 "ms_per_step": sec.item() / max(int(st.iterations), 1) * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": tok.item() / sec.item() / world / 123284.0, "dtype": "f32",
+                "scaling": "weak",
+                "vs_baseline": tok.item() / sec.item() / world / 123284.0 if ref_shape and args.engine_kind != "paged_bf16" else None,
+                "dtype": "bf16" if args.engine_kind == "paged_bf16" else "f32",
                 "data": "synthetic",
-                "config": {"workload": "engine: reference tests/paged_for_profile.cpp workload (B=1024 slots, S=128, "
-                                       "D=2048, V=1024, 4096 pages, 2048 items, prompt U[1,64]), "
-                                       f"{args.engine_kind} engine, ThroughputCounter tokens/s incl. host scheduling",
+                "config": {"workload": ("engine: reference tests/paged_for_profile.cpp workload" if ref_shape else
+                                        f"engine: {args.workload} shape under the reference's profiling recipe") +
+                                       f" (B={eB} slots, S={eS}, D={eD}, V={eV}, {e_blocks} pages, {2 * eB} items, "
+                                       f"prompt U[1,64]), {args.engine_kind} engine, ThroughputCounter tokens/s incl. "
+                                       "host scheduling, prefill, page growth and preemption",
                            "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
                            "reference_length_reset_quirk": bool(args.reference_quirk),
                            "total_tokens": tok.item(), "seconds": sec.item()}}))

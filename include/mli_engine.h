@@ -17,7 +17,10 @@ extern "C" {
 
 typedef struct mli_engine mli_engine;
 
-enum { MLI_ENGINE_CONTIGUOUS = 0, MLI_ENGINE_PAGED = 1, MLI_ENGINE_PAGED_GEMM = 2 };
+/* MLI_ENGINE_PAGED_BF16 is an EXTENSION (the reference is fp32 only): the paged GEMM engine over bf16 pages and
+ * bf16 Wk/Wq/Wv (the fp32 host weights are rounded to nearest-even at creation); emb_dim % 8 == 0; a page is
+ * 16 * 3 * emb_dim bf16 elements. */
+enum { MLI_ENGINE_CONTIGUOUS = 0, MLI_ENGINE_PAGED = 1, MLI_ENGINE_PAGED_GEMM = 2, MLI_ENGINE_PAGED_BF16 = 3 };
 
 typedef struct {
     int kind;             /* MLI_ENGINE_* */

@@ -175,8 +175,9 @@ int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* 
  * one visit per page; what A10 -> A4 -> A11 of SURVEY 8(a) compute together).  Inputs: q_output from
  * mli_get_latest_k_q_v_paged[_bf16]; outputs: qkt_output (probabilities, zero tail) and attention_result.
  * elem_bf16 selects the page element type; phases: 1 = scan kernel only, 2 = combine kernel only, 3 = both
- * (1 and 2 exist so the two launches can be timed apart).  Returns MLI_ERR_BAD_ARG when emb_dim needs more
- * than two 16-byte lane loads per row (fp32 > 512, bf16 > 1024): use the separate entry points then. */
+ * (1 and 2 exist so the two launches can be timed apart).  Rows of up to two 16-byte lane loads (fp32 <= 512,
+ * bf16 <= 1024) give every wave whole pages; wider rows (fp32 <= 2048, bf16 <= 4096) are split across the four
+ * waves of a workgroup.  Returns MLI_ERR_BAD_ARG beyond that: use the separate entry points then. */
 int mli_decode_scan_paged(const float* q_output, const void* const* page_table, const int* lengths,
                           float* qkt_output, float* attention_result, int n_batch, int n_sequence, int emb_dim,
                           int elem_bf16, int phases, void* workspace, size_t workspace_bytes, void* stream);
@@ -226,8 +227,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
  *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch
  *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
- *                      once for K and V, online softmax) when emb_dim fits two lane-loads per row (fp32 <= 512,
- *                      bf16 <= 1024); 0 = separate q.K^T / softmax / softmax.V passes
+ *                      once for K and V, online softmax) when emb_dim fits (fp32 <= 2048, bf16 <= 4096);
+ *                      0 = separate q.K^T / softmax / softmax.V passes
  *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
  *                      launches as the reference (qkt, softmax_in_place_with_lengths, softmax_v), -1 (default) =
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)

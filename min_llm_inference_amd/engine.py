@@ -9,7 +9,7 @@ import numpy as np
 
 from ._lib import EngineConfig, EngineStats, MliError, load_library
 
-CONTIGUOUS, PAGED, PAGED_GEMM = 0, 1, 2
+CONTIGUOUS, PAGED, PAGED_GEMM, PAGED_BF16 = 0, 1, 2, 3  # PAGED_BF16: extension, bf16 pages and weights
 
 
 def _fp(a):

@@ -4,6 +4,8 @@
 // own thread or process, and calls use_device() first.
 #pragma once
 
+#include <cstddef>
+
 namespace mli {
 namespace runtime {
 
@@ -12,6 +14,14 @@ int current_device();
 void set_compute_stream(void* stream); // hipStream_t as void*; nullptr = legacy default stream
 void* compute_stream();
 void synchronize();                    // hipStreamSynchronize(compute stream) / device sync for the default stream
+
+// Device scratch of the split-sequence attention kernels (mli_attention_workspace_bytes): one buffer per device,
+// grown on demand, owned by the host library because the C ABI never allocates.
+struct Scratch {
+    void* ptr;
+    size_t bytes;
+};
+Scratch attention_scratch(int n_batch, int n_sequence, int emb_dim);
 
 // roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
 void range_push(const char* name);

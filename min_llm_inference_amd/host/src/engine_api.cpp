@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "bf16_extension.h"
 #include "constants.h"
 #include "inference_model.h"
 #include "inferencer.h"
@@ -36,6 +37,7 @@ struct mli_engine {
     std::unique_ptr<InferenceModel> naive_model;
     std::unique_ptr<PagedAttentionInferenceModel> paged_model;
     std::unique_ptr<PagedAttentionCublasInferenceModel> gemm_model;
+    std::unique_ptr<PagedAttentionBf16InferenceModel> bf16_model;
     std::unique_ptr<MemoryBlockManager> pool;
     std::unique_ptr<PagedAttentionsManager> pages;
     TensorInt inp_device, inp_host, lengths_device, lengths_host, new_idx_device, new_idx_host;
@@ -56,6 +58,16 @@ struct mli_engine {
           new_idx_device({(size_t)c.n_batch}, DeviceType::DEVICE), new_idx_host({(size_t)c.n_batch}, DeviceType::HOST),
           result_device(result_shape(c), DeviceType::DEVICE), result_host(result_shape(c), DeviceType::HOST) {
         const size_t B = c.n_batch, S = c.n_sequence, D = c.emb_dim, V = c.n_vocab;
+        if (c.kind == MLI_ENGINE_PAGED_BF16) {
+            pool = std::make_unique<MemoryBlockManager>(c.n_blocks, bf16_page_block_floats(D));
+            pages = std::make_unique<PagedAttentionsManager>(B, S, D);
+            bf16_model = std::make_unique<PagedAttentionBf16InferenceModel>(
+                PagedAttentionBf16Layer(make_device_bf16(wk, {D, D}), make_device_bf16(wq, {D, D}),
+                                        make_device_bf16(wv, {D, D}), B, D, S),
+                B, S, D, V, c.n_forward_rounds);
+            init_loop_tensors(B, S);
+            return;
+        }
         TensorFloat dk = upload(wk, {D, D}), dq = upload(wq, {D, D}), dv = upload(wv, {D, D});
         if (c.kind == MLI_ENGINE_CONTIGUOUS) {
             naive_model = std::make_unique<InferenceModel>(
@@ -73,6 +85,10 @@ struct mli_engine {
                     PagedAttentionCublasLayer(std::move(dk), std::move(dq), std::move(dv), B, D, S),
                     PagedEncoderLayer(), PagedCublasDecoderLayer(B, V), B, S, D, c.n_forward_rounds);
         }
+        init_loop_tensors(B, S);
+    }
+
+    void init_loop_tensors(size_t B, size_t S) {
         std::memset(lengths_host.data(), 0, B * sizeof(int));
         std::memset(inp_host.data(), 0, B * S * sizeof(int));
         inp_device.copy_from(inp_host);
@@ -118,6 +134,9 @@ struct mli_engine {
         else if (cfg.kind == MLI_ENGINE_PAGED)
             paged_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                  pos_table, pages->get_page_table_device());
+        else if (cfg.kind == MLI_ENGINE_PAGED_BF16)
+            bf16_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
+                                pos_table, pages->get_page_table_device());
         else
             gemm_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                 pos_table, pages->get_page_table_device(), handle);
@@ -159,7 +178,7 @@ const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
 int mli_engine_create(const mli_engine_config* c, const float* emb_table, const float* pos_table, const float* wk,
                       const float* wq, const float* wv, mli_engine** out) {
     if (!c || !out || !emb_table || !pos_table || !wk || !wq || !wv) { g_last_error = "null argument"; return -1; }
-    if (c->kind < 0 || c->kind > 2 || c->n_batch <= 0 || c->n_sequence <= 0 || c->emb_dim <= 0 || c->emb_dim % 4 ||
+    if (c->kind < 0 || c->kind > 3 || (c->kind == MLI_ENGINE_PAGED_BF16 && c->emb_dim % 8) || c->n_batch <= 0 || c->n_sequence <= 0 || c->emb_dim <= 0 || c->emb_dim % 4 ||
         c->n_vocab <= EOF_TOKEN_ID ||
         (c->kind != MLI_ENGINE_CONTIGUOUS && (c->n_sequence % PAGE_BLOCK_SIZE || c->n_blocks <= 0 ||
                                               c->n_forward_rounds < 1 || c->n_forward_rounds > PAGE_BLOCK_SIZE)) ||

@@ -3,6 +3,7 @@
 #include <numeric>
 #include <vector>
 
+#include "bf16_extension.h"
 #include "runtime.h"
 #include "throughput_counter.h"
 
@@ -118,5 +119,20 @@ void start_paged_attention_cublas_inference_engine(const TensorFloat& emb_table,
                          inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
                                                  t.decoder_result_device, n_new_items, emb_table, pos_table,
                                                  paged_attention_manager.get_page_table_device(), handle);
+                     });
+}
+
+// EXTENSION (no reference counterpart): the same loop over bf16 pages and weights.
+void start_paged_attention_bf16_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table,
+                                                 ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                                 MemoryBlockManager& memory_block_manager,
+                                                 PagedAttentionsManager& paged_attention_manager,
+                                                 PagedAttentionBf16InferenceModel& inference_model,
+                                                 size_t n_batch_size, size_t n_sequence, int n_forward_rounds) {
+    run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
+                     n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
+                         inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
+                                                 t.decoder_result_device, n_new_items, emb_table, pos_table,
+                                                 paged_attention_manager.get_page_table_device());
                      });
 }

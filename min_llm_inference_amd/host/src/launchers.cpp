@@ -15,16 +15,9 @@
 #include "runtime.h"
 #include "utils.h"
 
-namespace {
-
 // Split-sequence scratch, one buffer per device, grown on demand (never shrinks).  It lives on the host
 // side because the C ABI itself never allocates.
-struct Scratch {
-    void* ptr;
-    size_t bytes;
-};
-
-Scratch scratch_for(int n_batch, int n_sequence, int dim) {
+mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequence, int dim) {
     static std::mutex mu;
     static std::map<int, std::unique_ptr<Tensor<char>>> per_device;
     const size_t need = mli_attention_workspace_bytes(n_batch, n_sequence, dim);
@@ -35,6 +28,13 @@ Scratch scratch_for(int n_batch, int n_sequence, int dim) {
         slot = std::make_unique<Tensor<char>>(std::vector<size_t>{need}, DeviceType::DEVICE,
                                               TensorDataType::SYNC_ALLOCATE);
     return {slot->data(), need};
+}
+
+namespace {
+
+using mli::runtime::Scratch;
+inline Scratch scratch_for(int n_batch, int n_sequence, int dim) {
+    return mli::runtime::attention_scratch(n_batch, n_sequence, dim);
 }
 
 inline void* stream() { return mli::runtime::compute_stream(); }

@@ -29,8 +29,16 @@ def make_items(seed, n_items, min_len, max_len, eof_token=1023):
 class CpuEngine:
     """Steppable form: one call to step() = one iteration of start_inference_engine's loop."""
 
-    def __init__(self, oracle, model, items, n_batch, n_sequence):
-        self.o, self.m = oracle, model
+    def __init__(self, oracle, model, items, n_batch, n_sequence, bf16=False):
+        """bf16 = True models the bf16 page extension: Wk/Wq/Wv and everything stored in a page (input embedding, K,
+        V) are rounded to bfloat16 where the GPU path stores them; q, scores, sums and logits stay fp32."""
+        self.o, self.m = oracle, dict(model)
+        self.bf16 = bf16
+        if bf16:
+            from helpers import bf16_round
+            self.round = bf16_round
+            for k in ("wk", "wq", "wv"):
+                self.m[k] = bf16_round(model[k])
         D = model["wk"].shape[0]
         V = model["emb_table"].shape[0]
         B, S = n_batch, n_sequence
@@ -72,8 +80,19 @@ class CpuEngine:
         o, m = self.o, self.m
         o.inference_optimized_encoder_host(m["emb_table"], m["pos_table"], self.inp, self.inp_emb, self.lengths,
                                            self.new_idx, self.n_new)
-        o.self_attention_inference_host(self.inp_emb, self.lengths, m["wk"], m["wq"], m["wv"], self.new_idx, self.kt,
-                                        self.v, self.q, self.qkt, self.att, self.n_new)
+        if not self.bf16:
+            o.self_attention_inference_host(self.inp_emb, self.lengths, m["wk"], m["wq"], m["wv"], self.new_idx,
+                                            self.kt, self.v, self.q, self.qkt, self.att, self.n_new)
+        else:
+            self.inp_emb[...] = self.round(self.inp_emb)
+            o.fill_new_kt_v_cache(self.inp_emb, self.new_idx, self.lengths, m["wk"], m["wv"], self.kt, self.v,
+                                  self.n_new)
+            o.get_latest_kt_q_v(self.inp_emb, self.lengths, m["wk"], m["wq"], m["wv"], self.kt, self.v, self.q)
+            self.kt[...] = self.round(self.kt)
+            self.v[...] = self.round(self.v)
+            o.qkt_host(self.q, self.kt, self.lengths, self.qkt)
+            o.softmax_in_place_with_lengths_host(self.qkt, self.lengths)
+            o.softmax_v_host(self.qkt, self.v, self.att, self.lengths)
         o.decoder_host(self.att, m["emb_table"], self.score, m["pos_table"], self.inp_emb, self.lengths, self.result)
         free_slots = []
         for b in range(self.B):
@@ -92,9 +111,9 @@ class CpuEngine:
         return self.result.copy()
 
 
-def run_cpu_engine(oracle, model, items, n_batch, n_sequence):
+def run_cpu_engine(oracle, model, items, n_batch, n_sequence, bf16=False):
     """Returns {item id: all tokens (prompt + generated)} and the number of iterations."""
-    e = CpuEngine(oracle, model, items, n_batch, n_sequence)
+    e = CpuEngine(oracle, model, items, n_batch, n_sequence, bf16=bf16)
     while not e.done():
         e.step()
     return e.finished, e.iterations
