@@ -18,6 +18,9 @@ Block* acquire(std::size_t bytes, Space space, Mode mode);
 void release(Block* block) noexcept;
 void* pointer(Block* block);                       // async blocks wait for their last copy first
 void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t bytes);  // same offset both sides
+// dst holds 8-byte elements: element index[i] = value[i] for i < n (index / value are host arrays).  Ordered like a
+// kernel on the compute stream (after earlier work, before later work); returns without waiting for it.
+void scatter8(Block* dst, const long long* index, const unsigned long long* value, std::size_t n);
 Space space_of(const Block* block);
 Mode mode_of(const Block* block);
 std::size_t size_of(const Block* block);

@@ -30,7 +30,11 @@ class PagedAttentionsManager {
 public:
     PagedAttentionsManager(size_t max_batches, size_t n_sequence, size_t emb_dim);
     std::list<BatchIdMemoryBlocksPair>& get_used_block_list();
-    void maybe_flush_changes();  // host page table -> device, only if something changed
+    // host page table -> device, only if something changed.  The reference re-uploads the whole table
+    // (src/paged_item_storage.cpp:181-186: 2 MiB at B=1024, S=4096, every iteration in which any row crosses a page
+    // boundary); here a few changed entries are scattered by one small kernel and only a bulk change (e.g. the
+    // initial admission of a whole batch) copies the table.
+    void maybe_flush_changes();
     void add_batch_block_pair(BatchIdMemoryBlocksPair&&);
     void set_block_pos(int batch_id, int i_block, float*);
     TensorFloatPoint& get_page_table_device();
@@ -42,6 +46,7 @@ private:
     std::list<BatchIdMemoryBlocksPair> used_blocks_;  // rows in admission order; the tail is preempted first
     size_t width_;                                    // n_sequence / PAGE_BLOCK_SIZE
     bool needs_sync_;
+    std::vector<long long> dirty_;                    // flat indices of entries changed since the last flush
 };
 
 // Gives the row one more page (and records it in the host page table).

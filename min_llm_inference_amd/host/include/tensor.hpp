@@ -58,6 +58,16 @@ public:
         mli::mem::copy(block_, other.block_, first * sizeof(T), count * sizeof(T));
     }
 
+    // Extension: element index[i] = value[i] for a handful of 8-byte elements (page-table entries) without
+    // re-uploading the tensor.
+    void scatter_from_host(const long long* index, const T* value, std::size_t n) {
+        static_assert(sizeof(T) == 8, "scatter_from_host handles 8-byte elements");
+        for (std::size_t i = 0; i < n; ++i)
+            if (index[i] < 0 || static_cast<std::size_t>(index[i]) >= count_)
+                throw std::runtime_error("scatter_from_host: index out of range");
+        mli::mem::scatter8(block_, index, reinterpret_cast<const unsigned long long*>(value), n);
+    }
+
 private:
     std::size_t count_;
     DeviceType device_;
@@ -85,6 +95,9 @@ public:
     void copy_from(const Tensor& other) { data_->copy_from(*other.data_); }
     void copy_range_from(const Tensor& other, std::size_t first, std::size_t count) {
         data_->copy_range_from(*other.data_, first, count);
+    }
+    void scatter_from_host(const long long* index, const T* value, std::size_t n) {
+        data_->scatter_from_host(index, value, n);
     }
     std::size_t get_total_size() const { return size_; }
 

@@ -1,5 +1,8 @@
 // extern "C" engine sessions (include/mli_engine.h): the reference's engine loops in resumable form, so a
 // host in another language -- or bench.py -- can step them and interleave the multi-GPU token gather.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iterator>
 #include <memory>
@@ -125,9 +128,15 @@ struct mli_engine {
 
     bool done() { return is_done(item_storage, processing_storage); }
 
+    double t_forward = 0, t_result = 0, t_pages = 0, t_insert = 0;  // host seconds per phase (MLI_ENGINE_TIMING=1)
+    static double now() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+
     void step() {
         if (!started) start();
         if (done()) return;
+        const double t0 = now();
         if (cfg.kind == MLI_ENGINE_CONTIGUOUS)
             naive_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                  pos_table);
@@ -140,12 +149,17 @@ struct mli_engine {
         else
             gemm_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                 pos_table, pages->get_page_table_device(), handle);
+        const double t1 = now();
         std::vector<int> free_slots =
             process_decoder_result(result_device, result_host, item_storage, processing_storage, cfg.n_sequence);
+        const double t2 = now();
         if (paged())
             allocate_or_free_memory_blocks_if_needed(*pages, *pool, processing_storage, item_storage, free_slots,
                                                      cfg.n_forward_rounds);
+        const double t3 = now();
         insert(free_slots);
+        const double t4 = now();
+        t_forward += t1 - t0; t_result += t2 - t1; t_pages += t3 - t2; t_insert += t4 - t3;
         ++iterations;
     }
 
@@ -192,7 +206,14 @@ int mli_engine_create(const mli_engine_config* c, const float* emb_table, const 
     })
 }
 
-void mli_engine_destroy(mli_engine* e) { delete e; }
+void mli_engine_destroy(mli_engine* e) {
+    if (e && std::getenv("MLI_ENGINE_TIMING") && e->iterations)
+        std::fprintf(stderr, "[mli engine] %lld iterations; host us/iteration: launch forward %.1f, wait + process "
+                     "decoder result %.1f, page bookkeeping %.1f, insert + uploads %.1f\n", e->iterations,
+                     1e6 * e->t_forward / e->iterations, 1e6 * e->t_result / e->iterations,
+                     1e6 * e->t_pages / e->iterations, 1e6 * e->t_insert / e->iterations);
+    delete e;
+}
 
 int mli_engine_add_item(mli_engine* e, int id, const int* tokens, int n_tokens) {
     if (!e || !tokens || n_tokens <= 0 || n_tokens + 1 > e->cfg.n_sequence) { g_last_error = "bad item"; return -1; }

@@ -163,6 +163,39 @@ void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t byt
     }
 }
 
+namespace {
+// the updates travel in the kernel arguments: no staging buffer, no copy, one launch per 128 entries
+constexpr int kScatterPerLaunch = 128;
+struct ScatterArgs {
+    long long index[kScatterPerLaunch];
+    unsigned long long value[kScatterPerLaunch];
+};
+__global__ void scatter8_kernel(unsigned long long* dst, ScatterArgs a, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[a.index[i]] = a.value[i];
+}
+}  // namespace
+
+void scatter8(Block* dst, const long long* index, const unsigned long long* value, std::size_t n) {
+    if (dst->space == Space::Host) {
+        for (std::size_t i = 0; i < n; ++i) static_cast<unsigned long long*>(dst->ptr)[index[i]] = value[i];
+        return;
+    }
+    wait_ready(dst);
+    hipStream_t st = static_cast<hipStream_t>(runtime::compute_stream());
+    for (std::size_t done = 0; done < n; done += kScatterPerLaunch) {
+        ScatterArgs a;
+        const int m = static_cast<int>(n - done < kScatterPerLaunch ? n - done : kScatterPerLaunch);
+        for (int i = 0; i < m; ++i) {
+            a.index[i] = index[done + i];
+            a.value[i] = value[done + i];
+        }
+        hipLaunchKernelGGL(scatter8_kernel, dim3(1), dim3(kScatterPerLaunch), 0, st,
+                           static_cast<unsigned long long*>(dst->ptr), a, m);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
 Space space_of(const Block* b) { return b->space; }
 Mode mode_of(const Block* b) { return b->mode; }
 std::size_t size_of(const Block* b) { return b->bytes; }

@@ -4,7 +4,6 @@
 #include <cassert>
 #include <iterator>
 #include <stdexcept>
-#include <unordered_set>
 
 #include "constants.h"
 #include "utils.h"
@@ -49,18 +48,33 @@ std::list<BatchIdMemoryBlocksPair>& PagedAttentionsManager::get_used_block_list(
 TensorFloatPoint& PagedAttentionsManager::get_page_table_device() { return page_table_device; }
 
 void PagedAttentionsManager::maybe_flush_changes() {
-    if (needs_sync_) page_table_device.copy_from(page_table_host);
+    constexpr size_t kScatterLimit = 512;  // beyond this one bulk copy is cheaper than the scatter launches
+    if (needs_sync_) {
+        if (dirty_.size() > kScatterLimit) {
+            page_table_device.copy_from(page_table_host);
+        } else {
+            std::vector<float*> values(dirty_.size());
+            for (size_t i = 0; i < dirty_.size(); ++i) values[i] = page_table_host.data()[dirty_[i]];
+            page_table_device.scatter_from_host(dirty_.data(), values.data(), dirty_.size());
+        }
+    }
+    dirty_.clear();
     needs_sync_ = false;
 }
 
 void PagedAttentionsManager::set_block_pos(int batch_id, int i_block, float* block) {
-    page_table_host.data()[static_cast<size_t>(batch_id) * width_ + i_block] = block;
+    const size_t at = static_cast<size_t>(batch_id) * width_ + i_block;
+    page_table_host.data()[at] = block;
+    dirty_.push_back(static_cast<long long>(at));
     needs_sync_ = true;
 }
 
 void PagedAttentionsManager::add_batch_block_pair(BatchIdMemoryBlocksPair&& row) {
     float** entry = page_table_host.data() + static_cast<size_t>(row.first) * width_;
-    for (float* block : row.second) *entry++ = block;
+    for (float* block : row.second) {
+        dirty_.push_back(static_cast<long long>(entry - page_table_host.data()));
+        *entry++ = block;
+    }
     used_blocks_.push_back(std::move(row));
     needs_sync_ = true;
 }
@@ -79,9 +93,16 @@ void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager& pages, Mem
     std::list<BatchIdMemoryBlocksPair>& rows = pages.get_used_block_list();
 
     // 1. finished rows hand their pages back
-    const std::unordered_set<int> finished(finished_indices.begin(), finished_indices.end());
-    for (auto it = rows.begin(); it != rows.end();) {
-        if (finished.count(it->first)) {
+    // (finished_indices also lists slots that were already empty; they own no row)
+    std::vector<int> sorted_copy;
+    const std::vector<int>* done = &finished_indices;  // process_decoder_result returns slots in ascending order
+    if (!std::is_sorted(done->begin(), done->end())) {
+        sorted_copy = finished_indices;
+        std::sort(sorted_copy.begin(), sorted_copy.end());
+        done = &sorted_copy;
+    }
+    for (auto it = rows.begin(); !done->empty() && it != rows.end();) {
+        if (std::binary_search(done->begin(), done->end(), it->first)) {
             pool.return_free_blocks(std::move(it->second));
             it = rows.erase(it);
         } else {
@@ -131,20 +152,24 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
     int* lengths = lengths_host.data();
     int* new_idx = new_items_indices_host.data();
 
-    std::unordered_set<int> occupied;
-    for (const BatchIdMemoryBlocksPair& row : pages.get_used_block_list()) occupied.insert(row.first);
+    std::vector<char> occupied(static_cast<size_t>(max_batch), 0);
+    for (const BatchIdMemoryBlocksPair& row : pages.get_used_block_list()) occupied[row.first] = 1;
 
     std::vector<int> inserted;
     bool dirty = false;
     for (int slot = 0; slot < max_batch; ++slot) {
-        if (occupied.count(slot)) {
+        if (occupied[slot]) {
             // in-flight row: its device length equals its host token count (see src/item_storage.cpp);
             // the reference leaves the stale insertion-time value here (quirk, off by default)
             if (!g_length_reset_quirk)
                 lengths[slot] = static_cast<int>(processing_storage.get_token(slot).second.size());
             continue;
         }
-        dirty = true;
+        // A free slot whose mirrored length is already 0 was free at the last upload too, and the device agrees
+        // (the decoder zeroes finished rows itself): nothing to upload for it.  A non-zero mirror means the row
+        // left since then -- finished, or preempted with its device length still live -- so the lengths go up.
+        // (The reference uploads whenever any slot is free; kept under the quirk switch.)
+        if (lengths[slot] != 0 || g_length_reset_quirk) dirty = true;
         const int width = pages.max_blocks_per_row();
         const bool can_admit = pool.free_blocks_size() >= DEFAULT_INIT_NUM_BLOCKS && item_storage.new_count() > 0 &&
                                pool.free_blocks_size() >= std::min(width, ceil_div(item_storage.head_length() + n_forward_rounds, PAGE_BLOCK_SIZE));
@@ -156,6 +181,7 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
         const int n_tokens = static_cast<int>(item.second.size());
         assert(n_tokens + 1 <= n_sequence);
         lengths[slot] = n_tokens;
+        dirty = true;
         std::copy(item.second.begin(), item.second.end(), inp + static_cast<size_t>(slot) * n_sequence);
         new_idx[inserted.size()] = slot;
         const int n_pages = std::min(width, std::max(ceil_div(n_tokens + n_forward_rounds, PAGE_BLOCK_SIZE), DEFAULT_INIT_NUM_BLOCKS));
@@ -164,10 +190,8 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
         inserted.push_back(slot);
     }
     upload_changed_rows(inp_device, inp_host, inserted, lengths, n_sequence);
-    if (dirty) {
-        lengths_device.copy_from(lengths_host);
-        new_items_indices_device.copy_from(new_items_indices_host);
-    }
+    if (dirty) lengths_device.copy_from(lengths_host);
+    if (!inserted.empty() || g_length_reset_quirk) new_items_indices_device.copy_from(new_items_indices_host);
     pages.maybe_flush_changes();
     return inserted;
 }

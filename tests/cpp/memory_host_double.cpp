@@ -42,6 +42,12 @@ void copy(Block* dst, const Block* src, std::size_t off, std::size_t bytes) {
     if (off + bytes > dst->bytes || off + bytes > src->bytes) throw std::runtime_error("copy out of range");
     std::memcpy(static_cast<char*>(dst->ptr) + off, static_cast<const char*>(src->ptr) + off, bytes);
 }
+void scatter8(Block* dst, const long long* index, const unsigned long long* value, std::size_t n) {
+    for (std::size_t i = 0; i < n; ++i) {
+        if (static_cast<std::size_t>(index[i]) * 8 + 8 > dst->bytes) throw std::runtime_error("scatter out of range");
+        static_cast<unsigned long long*>(dst->ptr)[index[i]] = value[i];
+    }
+}
 Space space_of(const Block* b) { return b->space; }
 Mode mode_of(const Block* b) { return b->mode; }
 std::size_t size_of(const Block* b) { return b->bytes; }
