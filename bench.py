@@ -314,14 +314,43 @@ def run_engine_mode(args, rank, world, dev):
     # page pool: the reference gives 4 pages per slot at S = 128, i.e. half of the worst case B * S / 16 -- rows
     # outgrow it, so page growth and preemption are part of the measured run (mode E)
     n_blocks = B * S // 32
-    e = eng.Engine(kind, B, S, D, V, emb, u(S, D), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)),
-                   u(D, D, scale=1 / np.sqrt(D)), n_blocks=n_blocks, n_forward_rounds=1, device=dev.index,
-                   reference_length_reset_quirk=args.reference_quirk)
-    for i in range(2 * B):
-        e.add_item(i, rng.integers(0, ops.EOF_TOKEN_ID, size=int(rng.integers(1, 65))))
-    st = e.run()
-    assert st.finished == 2 * B
-    return st, (B, S, D, V, n_blocks)
+    R = max(1, args.engine_replicas)
+    assert B % R == 0
+    weights = (emb, u(S, D), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)))
+    items = [(i, rng.integers(0, ops.EOF_TOKEN_ID, size=int(rng.integers(1, 65)))) for i in range(2 * B)]
+    engines = []
+    for r in range(R):  # R engines of B / R slots each share the GPU (private streams, one host thread each)
+        e = eng.Engine(kind, B // R, S, D, V, *weights, n_blocks=n_blocks // R, n_forward_rounds=1, device=dev.index,
+                       reference_length_reset_quirk=args.reference_quirk)
+        if R > 1:
+            e.use_private_stream()
+        if args.pipelined:
+            e.set_pipelined()
+        for i, toks in items[r::R]:
+            e.add_item(i, toks)
+        engines.append(e)
+    if R == 1:
+        st = engines[0].run()
+        assert st.finished == 2 * B
+        return st, (B, S, D, V, n_blocks)
+    import threading
+    stats = [None] * R
+    def drive(r):
+        stats[r] = engines[r].run()
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(R)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    wall = time.perf_counter() - t0
+    assert sum(s.finished for s in stats) == 2 * B
+
+    class Total:  # whole-GPU totals: tokens of all engines over the wall time of the slowest
+        total_tokens = sum(s.total_tokens for s in stats)
+        seconds = max(max(s.seconds for s in stats), wall)
+        iterations = max(s.iterations for s in stats)
+    return Total, (B, S, D, V, n_blocks)
 
 
 def main():
@@ -339,6 +368,11 @@ def main():
                     help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
     ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16"], default="paged_gemm",
                     help="paged_bf16 = extension: bf16 pages and weights (BASELINE config 4 dtype)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="engine mode: the pipelined loop (host one step behind the GPU; per-slot device updates)")
+    ap.add_argument("--engine-replicas", type=int, default=1,
+                    help="engine mode: split the slots over this many engines on the same GPU (private streams, one "
+                         "host thread each) so one engine's host bookkeeping overlaps the other's kernels")
     ap.add_argument("--engine-shape", action="store_true",
                     help="engine mode: run the --workload shape (e.g. c4) instead of the reference's profiling shape e1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
@@ -389,7 +423,7 @@ def main():
                 "config": {"workload": ("engine: reference tests/paged_for_profile.cpp workload" if ref_shape else
                                         f"engine: {args.workload} shape under the reference's profiling recipe") +
                                        f" (B={eB} slots, S={eS}, D={eD}, V={eV}, {e_blocks} pages, {2 * eB} items, "
-                                       f"prompt U[1,64]), {args.engine_kind} engine, ThroughputCounter tokens/s incl. "
+                                       f"prompt U[1,64]), {args.engine_kind} engine x{args.engine_replicas}{' pipelined' if args.pipelined else ''}, ThroughputCounter tokens/s incl. "
                                        "host scheduling, prefill, page growth and preemption",
                            "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
                            "reference_length_reset_quirk": bool(args.reference_quirk),

@@ -50,6 +50,20 @@ int mli_engine_create(const mli_engine_config* config, const float* emb_table, c
                       const float* wk, const float* wq, const float* wv, mli_engine** out);
 void mli_engine_destroy(mli_engine* engine);
 
+/* Give the engine its own non-blocking HIP stream (default: the calling thread's stream, i.e. the legacy default
+ * stream, as the reference).  Engines with private streams can be driven from different threads of one process
+ * and overlap on one GPU: while one waits for its decoder result and does its host bookkeeping, the other's
+ * kernels run.  Each engine has its own ThroughputCounter, scratch and page pool; an engine is driven by one
+ * thread at a time. */
+int mli_engine_use_private_stream(mli_engine* engine);
+
+/* EXTENSION: make mli_engine_run use the pipelined loop of the paged kinds -- the host works one
+ * step behind the GPU (page growth and admission for step k+1 while step k's result is still in flight; per-slot
+ * device updates instead of whole-tensor uploads), min_llm_inference_amd/host/include/pipelined_engine.h.  Per-item
+ * token streams are identical to the sequential loop's.  n_forward_rounds must be 1; call before the first run;
+ * mli_engine_step is not available on a pipelined engine. */
+int mli_engine_set_pipelined(mli_engine* engine, int enabled);
+
 /* Queue one item (ItemStorage::add_new_item). */
 int mli_engine_add_item(mli_engine* engine, int id, const int* tokens, int n_tokens);
 

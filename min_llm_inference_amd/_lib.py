@@ -87,6 +87,8 @@ ENGINE_SIGNATURES = {
     "mli_engine_create": [ctypes.POINTER(EngineConfig), _P, _P, _P, _P, _P, _PP],
     "mli_engine_destroy": [_P],
     "mli_engine_add_item": [_P, _I, _P, _I],
+    "mli_engine_use_private_stream": [_P],
+    "mli_engine_set_pipelined": [_P, _I],
     "mli_engine_run": [_P, ctypes.POINTER(EngineStats)],
     "mli_engine_step": [_P, _IP],
     "mli_engine_get_stats": [_P, ctypes.POINTER(EngineStats)],

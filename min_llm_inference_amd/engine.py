@@ -32,6 +32,12 @@ class Engine:
         if rc != 0:
             raise MliError("Hip Failure: " + (self._lib.mli_engine_last_error() or b"").decode())
 
+    def use_private_stream(self):
+        self._check(self._lib.mli_engine_use_private_stream(self._h))
+
+    def set_pipelined(self, enabled=True):
+        self._check(self._lib.mli_engine_set_pipelined(self._h, int(enabled)))
+
     def add_item(self, item_id, tokens):
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         self._check(self._lib.mli_engine_add_item(self._h, int(item_id), t.ctypes.data_as(ctypes.c_void_p), len(t)))

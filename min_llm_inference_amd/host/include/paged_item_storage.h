@@ -58,6 +58,18 @@ void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager&, MemoryBlo
                                               ItemStorage&, const std::vector<int>& finished_indices,
                                               int n_forward_rounds);
 
+// The host-only half of the paged insert: admission decisions, page hand-out, host mirrors (inp rows, lengths,
+// new_idx[0 .. slots.size())) -- no device traffic.  insert_new_items = this + the uploads; the pipelined engine
+// (pipelined_engine.h) pairs it with per-slot device updates instead.
+struct PagedAdmission {
+    std::vector<int> slots;        // slots filled, in slot order
+    bool lengths_changed = false;  // some slot's length differs from what the device holds
+};
+PagedAdmission admit_new_items(int* inp_host, int* lengths_host, int* new_idx_host, int max_batch, int n_sequence,
+                               ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                               MemoryBlockManager& memory_block_manager,
+                               PagedAttentionsManager& paged_attention_manager, int n_forward_rounds);
+
 // Paged engine: admit queued items into free slots while pages last; returns the slots filled.
 std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, TensorInt& lengths_device,
                                   TensorInt& lengths_host, TensorInt& new_items_indices_device,

@@ -13,6 +13,8 @@ void use_device(int ordinal);          // hipSetDevice for the calling thread
 int current_device();
 void set_compute_stream(void* stream); // hipStream_t as void*; nullptr = legacy default stream
 void* compute_stream();
+void* create_stream();                  // a non-blocking stream for one engine (several engines per GPU overlap)
+void destroy_stream(void* stream) noexcept;
 void synchronize();                    // hipStreamSynchronize(compute stream) / device sync for the default stream
 
 // Device scratch of the split-sequence attention kernels (mli_attention_workspace_bytes): one buffer per device,

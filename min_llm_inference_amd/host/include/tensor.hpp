@@ -61,11 +61,22 @@ public:
     // Extension: element index[i] = value[i] for a handful of 8-byte elements (page-table entries) without
     // re-uploading the tensor.
     void scatter_from_host(const long long* index, const T* value, std::size_t n) {
-        static_assert(sizeof(T) == 8, "scatter_from_host handles 8-byte elements");
+        static_assert(sizeof(T) == 8 || sizeof(T) == 4, "scatter_from_host handles 4- and 8-byte elements");
         for (std::size_t i = 0; i < n; ++i)
             if (index[i] < 0 || static_cast<std::size_t>(index[i]) >= count_)
                 throw std::runtime_error("scatter_from_host: index out of range");
-        mli::mem::scatter8(block_, index, reinterpret_cast<const unsigned long long*>(value), n);
+        if constexpr (sizeof(T) == 8)
+            mli::mem::scatter8(block_, index, reinterpret_cast<const unsigned long long*>(value), n);
+        else
+            mli::mem::scatter4(block_, index, reinterpret_cast<const unsigned int*>(value), n);
+    }
+
+    // Extension: stream-ordered copy of elements [first, first + count) that does not block the host (memory.h
+    // copy_async: pinned host side, source unchanged until a later marker has been waited for).
+    void copy_range_from_async(const TensorData& other, std::size_t first, std::size_t count) {
+        if (other.count_ != count_ || first + count > count_)
+            throw std::runtime_error("Copy from: shape or device mismatch");
+        mli::mem::copy_async(block_, other.block_, first * sizeof(T), count * sizeof(T));
     }
 
 private:
@@ -98,6 +109,9 @@ public:
     }
     void scatter_from_host(const long long* index, const T* value, std::size_t n) {
         data_->scatter_from_host(index, value, n);
+    }
+    void copy_range_from_async(const Tensor& other, std::size_t first, std::size_t count) {
+        data_->copy_range_from_async(*other.data_, first, count);
     }
     std::size_t get_total_size() const { return size_; }
 

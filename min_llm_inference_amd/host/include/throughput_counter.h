@@ -23,3 +23,7 @@ private:
 };
 
 ThroughputCounter& get_global_throughput_counter();
+
+// Extension: route the calling thread's records to `counter` (nullptr = back to the process-wide one), so several
+// engines can run in one process, one thread each, without sharing the reference's singleton.
+void set_thread_throughput_counter(ThroughputCounter* counter);

@@ -15,6 +15,7 @@
 #include "inference_model.h"
 #include "inferencer.h"
 #include "mli_engine.h"
+#include "pipelined_engine.h"
 #include "runtime.h"
 #include "throughput_counter.h"
 
@@ -49,6 +50,25 @@ struct mli_engine {
     int n_new_items = 0;
     long long iterations = 0;
     GemmHandle handle;
+    ThroughputCounter counter;  // this engine's own (the reference has one per process)
+    bool pipelined = false;     // mli_engine_set_pipelined: run() uses the pipelined loop (pipelined_engine.h)
+    void* stream = nullptr;     // private compute stream (mli_engine_use_private_stream), else the thread's
+
+    ~mli_engine() { mli::runtime::destroy_stream(stream); }
+
+    // every entry point runs under this: device, stream and counter of THIS engine for the calling thread
+    struct Scope {
+        void* saved;
+        explicit Scope(mli_engine* e) : saved(mli::runtime::compute_stream()) {
+            mli::runtime::use_device(e->cfg.device);
+            if (e->stream) mli::runtime::set_compute_stream(e->stream);
+            set_thread_throughput_counter(&e->counter);
+        }
+        ~Scope() {
+            mli::runtime::set_compute_stream(saved);
+            set_thread_throughput_counter(nullptr);
+        }
+    };
 
     mli_engine(const mli_engine_config& c, const float* emb, const float* pos, const float* wk, const float* wq,
                const float* wv)
@@ -127,6 +147,28 @@ struct mli_engine {
     }
 
     bool done() { return is_done(item_storage, processing_storage); }
+
+    void run_pipelined() {
+        if (started) throw std::runtime_error("pipelined run on an engine that has already been stepped");
+        if (!paged() || cfg.n_forward_rounds != 1)
+            throw std::runtime_error("the pipelined loop serves the paged kinds with n_forward_rounds = 1");
+        set_reference_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
+        get_global_throughput_counter().reset();
+        started = true;
+        iterations = run_paged_engine_pipelined(
+            item_storage, processing_storage, *pool, *pages, cfg.n_batch, cfg.n_sequence,
+            [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
+                if (cfg.kind == MLI_ENGINE_PAGED)
+                    paged_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                         pages->get_page_table_device());
+                else if (cfg.kind == MLI_ENGINE_PAGED_BF16)
+                    bf16_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                        pages->get_page_table_device());
+                else
+                    gemm_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                        pages->get_page_table_device(), handle);
+            });
+    }
 
     double t_forward = 0, t_result = 0, t_pages = 0, t_insert = 0;  // host seconds per phase (MLI_ENGINE_TIMING=1)
     static double now() {
@@ -207,7 +249,7 @@ int mli_engine_create(const mli_engine_config* c, const float* emb_table, const 
 }
 
 void mli_engine_destroy(mli_engine* e) {
-    if (e && std::getenv("MLI_ENGINE_TIMING") && e->iterations)
+    if (e && std::getenv("MLI_ENGINE_TIMING") && e->iterations && !e->pipelined)
         std::fprintf(stderr, "[mli engine] %lld iterations; host us/iteration: launch forward %.1f, wait + process "
                      "decoder result %.1f, page bookkeeping %.1f, insert + uploads %.1f\n", e->iterations,
                      1e6 * e->t_forward / e->iterations, 1e6 * e->t_result / e->iterations,
@@ -220,9 +262,24 @@ int mli_engine_add_item(mli_engine* e, int id, const int* tokens, int n_tokens) 
     MLI_GUARD(e->item_storage.add_new_item(std::make_pair(id, std::vector<int>(tokens, tokens + n_tokens))))
 }
 
-int mli_engine_step(mli_engine* e, int* done) {
+int mli_engine_use_private_stream(mli_engine* e) {
     MLI_GUARD({
         mli::runtime::use_device(e->cfg.device);
+        if (!e->stream) e->stream = mli::runtime::create_stream();
+    })
+}
+
+int mli_engine_set_pipelined(mli_engine* e, int enabled) {
+    MLI_GUARD({
+        if (e->started) throw std::runtime_error("set_pipelined after the engine has started");
+        e->pipelined = enabled != 0;
+    })
+}
+
+int mli_engine_step(mli_engine* e, int* done) {
+    MLI_GUARD({
+        if (e->pipelined) throw std::runtime_error("a pipelined engine is run to completion (mli_engine_run)");
+        mli_engine::Scope scope(e);
         e->step();
         if (done) *done = e->done() ? 1 : 0;
     })
@@ -230,14 +287,23 @@ int mli_engine_step(mli_engine* e, int* done) {
 
 int mli_engine_run(mli_engine* e, mli_engine_stats* stats) {
     MLI_GUARD({
-        mli::runtime::use_device(e->cfg.device);
-        if (!e->started) e->start();
-        while (!e->done()) e->step();
+        mli_engine::Scope scope(e);
+        if (e->pipelined) {
+            e->run_pipelined();
+        } else {
+            if (!e->started) e->start();
+            while (!e->done()) e->step();
+        }
         if (stats) e->fill(stats);
     })
 }
 
-int mli_engine_get_stats(mli_engine* e, mli_engine_stats* stats) { MLI_GUARD(e->fill(stats)) }
+int mli_engine_get_stats(mli_engine* e, mli_engine_stats* stats) {
+    MLI_GUARD({
+        mli_engine::Scope scope(e);
+        e->fill(stats);
+    })
+}
 
 int mli_engine_decoder_result(mli_engine* e, void** device_ptr, int* count) {
     MLI_GUARD({

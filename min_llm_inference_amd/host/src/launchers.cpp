@@ -15,15 +15,16 @@
 #include "runtime.h"
 #include "utils.h"
 
-// Split-sequence scratch, one buffer per device, grown on demand (never shrinks).  It lives on the host
+// Split-sequence scratch, one buffer per (device, compute stream) -- kernels of two streams may run at the same
+// time --, grown on demand (never shrinks).  It lives on the host
 // side because the C ABI itself never allocates.
 mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequence, int dim) {
     static std::mutex mu;
-    static std::map<int, std::unique_ptr<Tensor<char>>> per_device;
+    static std::map<std::pair<int, void*>, std::unique_ptr<Tensor<char>>> per_device;  // (device, stream)
     const size_t need = mli_attention_workspace_bytes(n_batch, n_sequence, dim);
     if (need == 0) return {nullptr, 0};
     std::lock_guard<std::mutex> lock(mu);
-    auto& slot = per_device[mli::runtime::current_device()];
+    auto& slot = per_device[{mli::runtime::current_device(), mli::runtime::compute_stream()}];
     if (!slot || slot->get_total_size() < need)
         slot = std::make_unique<Tensor<char>>(std::vector<size_t>{need}, DeviceType::DEVICE,
                                               TensorDataType::SYNC_ALLOCATE);

@@ -52,6 +52,15 @@ void synchronize() {
     else HIP_CHECK(hipDeviceSynchronize());
 }
 
+void* create_stream() {
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+void destroy_stream(void* stream) noexcept {
+    if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
+
 void range_push(const char* name) { roctxRangePushA(name); }
 void range_pop() { roctxRangePop(); }
 
@@ -154,7 +163,15 @@ void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t byt
     char* d = static_cast<char*>(dst->ptr) + byte_offset;
     const char* f = static_cast<const char*>(s->ptr) + byte_offset;
     if (dst->mode == Mode::Sync) {
-        HIP_CHECK(hipMemcpy(d, f, bytes, kind));
+        // With a private compute stream the copy must be ordered with THAT stream's kernels (hipMemcpy only orders
+        // with the legacy default stream and would serialise against every other engine in the process).
+        hipStream_t cs = static_cast<hipStream_t>(runtime::compute_stream());
+        if (cs == nullptr) {
+            HIP_CHECK(hipMemcpy(d, f, bytes, kind));
+        } else {
+            HIP_CHECK(hipMemcpyAsync(d, f, bytes, kind, cs));
+            HIP_CHECK(hipStreamSynchronize(cs));
+        }
     } else {
         wait_ready(s);
         wait_ready(dst);
@@ -170,15 +187,16 @@ struct ScatterArgs {
     long long index[kScatterPerLaunch];
     unsigned long long value[kScatterPerLaunch];
 };
-__global__ void scatter8_kernel(unsigned long long* dst, ScatterArgs a, int n) {
+template <typename T>
+__global__ void scatter_kernel(T* dst, ScatterArgs a, int n) {
     const int i = threadIdx.x;
-    if (i < n) dst[a.index[i]] = a.value[i];
+    if (i < n) dst[a.index[i]] = static_cast<T>(a.value[i]);
 }
-}  // namespace
 
-void scatter8(Block* dst, const long long* index, const unsigned long long* value, std::size_t n) {
+template <typename T>
+void scatter_impl(Block* dst, const long long* index, const T* value, std::size_t n) {
     if (dst->space == Space::Host) {
-        for (std::size_t i = 0; i < n; ++i) static_cast<unsigned long long*>(dst->ptr)[index[i]] = value[i];
+        for (std::size_t i = 0; i < n; ++i) static_cast<T*>(dst->ptr)[index[i]] = value[i];
         return;
     }
     wait_ready(dst);
@@ -190,10 +208,43 @@ void scatter8(Block* dst, const long long* index, const unsigned long long* valu
             a.index[i] = index[done + i];
             a.value[i] = value[done + i];
         }
-        hipLaunchKernelGGL(scatter8_kernel, dim3(1), dim3(kScatterPerLaunch), 0, st,
-                           static_cast<unsigned long long*>(dst->ptr), a, m);
+        hipLaunchKernelGGL(scatter_kernel<T>, dim3(1), dim3(kScatterPerLaunch), 0, st, static_cast<T*>(dst->ptr), a, m);
         HIP_CHECK(hipGetLastError());
     }
+}
+}  // namespace
+
+struct Marker {
+    hipEvent_t event = nullptr;
+};
+
+Marker* create_marker() {
+    Marker* m = new Marker;
+    HIP_CHECK(hipEventCreateWithFlags(&m->event, hipEventDisableTiming));
+    return m;
+}
+void destroy_marker(Marker* m) noexcept {
+    if (m == nullptr) return;
+    (void)hipEventDestroy(m->event);
+    delete m;
+}
+void record_marker(Marker* m) { HIP_CHECK(hipEventRecord(m->event, static_cast<hipStream_t>(runtime::compute_stream()))); }
+void wait_marker(Marker* m) { HIP_CHECK(hipEventSynchronize(m->event)); }
+
+void copy_async(Block* dst, const Block* src, std::size_t byte_offset, std::size_t bytes) {
+    if (bytes == 0) return;
+    if (dst->mode != Mode::Sync || src->mode != Mode::Sync)
+        throw std::runtime_error("copy_async: sync-flavour blocks only");
+    HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dst->ptr) + byte_offset,
+                             static_cast<const char*>(src->ptr) + byte_offset, bytes, kind_of(dst->space, src->space),
+                             static_cast<hipStream_t>(runtime::compute_stream())));
+}
+
+void scatter8(Block* dst, const long long* index, const unsigned long long* value, std::size_t n) {
+    scatter_impl<unsigned long long>(dst, index, value, n);
+}
+void scatter4(Block* dst, const long long* index, const unsigned int* value, std::size_t n) {
+    scatter_impl<unsigned int>(dst, index, value, n);
 }
 
 Space space_of(const Block* b) { return b->space; }

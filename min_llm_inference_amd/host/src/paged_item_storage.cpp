@@ -140,23 +140,14 @@ void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager& pages, Mem
     }
 }
 
-std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, TensorInt& lengths_device,
-                                  TensorInt& lengths_host, TensorInt& new_items_indices_device,
-                                  TensorInt& new_items_indices_host, ItemStorage& item_storage,
-                                  ProcessingStorage& processing_storage, MemoryBlockManager& pool,
-                                  PagedAttentionsManager& pages, int n_forward_rounds) {
+PagedAdmission admit_new_items(int* inp, int* lengths, int* new_idx, int max_batch, int n_sequence,
+                               ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                               MemoryBlockManager& pool, PagedAttentionsManager& pages, int n_forward_rounds) {
     assert(n_forward_rounds > 0 && n_forward_rounds <= PAGE_BLOCK_SIZE);
-    const int max_batch = static_cast<int>(inp_device.shape()[0]);
-    const int n_sequence = static_cast<int>(inp_device.shape()[1]);
-    int* inp = inp_host.data();
-    int* lengths = lengths_host.data();
-    int* new_idx = new_items_indices_host.data();
-
     std::vector<char> occupied(static_cast<size_t>(max_batch), 0);
     for (const BatchIdMemoryBlocksPair& row : pages.get_used_block_list()) occupied[row.first] = 1;
 
-    std::vector<int> inserted;
-    bool dirty = false;
+    PagedAdmission result;
     for (int slot = 0; slot < max_batch; ++slot) {
         if (occupied[slot]) {
             // in-flight row: its device length equals its host token count (see src/item_storage.cpp);
@@ -169,7 +160,7 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
         // (the decoder zeroes finished rows itself): nothing to upload for it.  A non-zero mirror means the row
         // left since then -- finished, or preempted with its device length still live -- so the lengths go up.
         // (The reference uploads whenever any slot is free; kept under the quirk switch.)
-        if (lengths[slot] != 0 || g_length_reset_quirk) dirty = true;
+        if (lengths[slot] != 0 || g_length_reset_quirk) result.lengths_changed = true;
         const int width = pages.max_blocks_per_row();
         const bool can_admit = pool.free_blocks_size() >= DEFAULT_INIT_NUM_BLOCKS && item_storage.new_count() > 0 &&
                                pool.free_blocks_size() >= std::min(width, ceil_div(item_storage.head_length() + n_forward_rounds, PAGE_BLOCK_SIZE));
@@ -181,17 +172,29 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
         const int n_tokens = static_cast<int>(item.second.size());
         assert(n_tokens + 1 <= n_sequence);
         lengths[slot] = n_tokens;
-        dirty = true;
+        result.lengths_changed = true;
         std::copy(item.second.begin(), item.second.end(), inp + static_cast<size_t>(slot) * n_sequence);
-        new_idx[inserted.size()] = slot;
+        new_idx[result.slots.size()] = slot;
         const int n_pages = std::min(width, std::max(ceil_div(n_tokens + n_forward_rounds, PAGE_BLOCK_SIZE), DEFAULT_INIT_NUM_BLOCKS));
         processing_storage.put(slot, std::move(item));
         pages.add_batch_block_pair(std::make_pair(slot, pool.pop_free_blocks(n_pages)));
-        inserted.push_back(slot);
+        result.slots.push_back(slot);
     }
-    upload_changed_rows(inp_device, inp_host, inserted, lengths, n_sequence);
-    if (dirty) lengths_device.copy_from(lengths_host);
-    if (!inserted.empty() || g_length_reset_quirk) new_items_indices_device.copy_from(new_items_indices_host);
+    return result;
+}
+
+std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, TensorInt& lengths_device,
+                                  TensorInt& lengths_host, TensorInt& new_items_indices_device,
+                                  TensorInt& new_items_indices_host, ItemStorage& item_storage,
+                                  ProcessingStorage& processing_storage, MemoryBlockManager& pool,
+                                  PagedAttentionsManager& pages, int n_forward_rounds) {
+    const int max_batch = static_cast<int>(inp_device.shape()[0]);
+    const int n_sequence = static_cast<int>(inp_device.shape()[1]);
+    PagedAdmission adm = admit_new_items(inp_host.data(), lengths_host.data(), new_items_indices_host.data(), max_batch,
+                                         n_sequence, item_storage, processing_storage, pool, pages, n_forward_rounds);
+    upload_changed_rows(inp_device, inp_host, adm.slots, lengths_host.data(), n_sequence);
+    if (adm.lengths_changed) lengths_device.copy_from(lengths_host);
+    if (!adm.slots.empty() || g_length_reset_quirk) new_items_indices_device.copy_from(new_items_indices_host);
     pages.maybe_flush_changes();
-    return inserted;
+    return adm.slots;
 }

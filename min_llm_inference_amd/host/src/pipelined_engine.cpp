@@ -1,0 +1,199 @@
+#include "pipelined_engine.h"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "constants.h"
+#include "runtime.h"
+#include "throughput_counter.h"
+
+namespace {
+
+struct Range {  // roctx range, closed on scope exit
+    explicit Range(const char* name) { mli::runtime::range_push(name); }
+    ~Range() { mli::runtime::range_pop(); }
+};
+
+struct MarkerHandle {
+    mli::mem::Marker* m;
+    MarkerHandle() : m(mli::mem::create_marker()) {}
+    ~MarkerHandle() { mli::mem::destroy_marker(m); }
+    MarkerHandle(const MarkerHandle&) = delete;
+    MarkerHandle& operator=(const MarkerHandle&) = delete;
+};
+
+}  // namespace
+
+long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                     MemoryBlockManager& pool, PagedAttentionsManager& pages, size_t n_batch_size,
+                                     size_t n_sequence, const PagedForward& forward) {
+    if (reference_length_reset_quirk())
+        throw std::runtime_error("the pipelined engine does not reproduce the reference's length-reset quirk");
+    const int B = static_cast<int>(n_batch_size), S = static_cast<int>(n_sequence);
+    TensorInt inp_device({n_batch_size, n_sequence}, DeviceType::DEVICE), inp_host({n_batch_size, n_sequence}, DeviceType::HOST);
+    TensorInt lengths_device({n_batch_size}, DeviceType::DEVICE), lengths_host({n_batch_size}, DeviceType::HOST);
+    TensorInt new_idx_device({n_batch_size}, DeviceType::DEVICE);
+    // staging for the new-row indices of forward(k) is reused for forward(k+2): by then the marker of step k+1,
+    // recorded after forward(k+1) was queued, has been waited for, so the copy that fed forward(k) has executed
+    TensorInt new_idx_host[2] = {TensorInt({n_batch_size}, DeviceType::HOST), TensorInt({n_batch_size}, DeviceType::HOST)};
+    TensorInt result_device({n_batch_size, 1}, DeviceType::DEVICE), result_host({n_batch_size, 1}, DeviceType::HOST);
+    MarkerHandle marker;
+
+    // first_step[b] = index of the first forward this occupant of slot b takes part in; -1 = slot empty
+    std::vector<long long> first_step(n_batch_size, -1);
+    std::vector<long long> idx;
+    std::vector<int> val;
+
+    std::memset(lengths_host.data(), 0, n_batch_size * sizeof(int));
+    lengths_device.copy_from(lengths_host);
+    get_global_throughput_counter().start_record();
+
+    // admission for forward `step`: host decisions, then per-slot, stream-ordered, non-blocking device updates
+    auto admit = [&](long long step) {
+        Range r("insert_new_items");
+        TensorInt& staging = new_idx_host[step & 1];
+        PagedAdmission adm = admit_new_items(inp_host.data(), lengths_host.data(), staging.data(), B, S, item_storage,
+                                             processing_storage, pool, pages, /*n_forward_rounds=*/1);
+        if (adm.slots.empty()) {
+            pages.maybe_flush_changes();
+            return 0;
+        }
+        idx.clear();
+        val.clear();
+        for (int slot : adm.slots) {
+            first_step[slot] = step;
+            idx.push_back(slot);
+            val.push_back(lengths_host.data()[slot]);
+        }
+        if (adm.slots.size() <= 8) {
+            for (int slot : adm.slots)
+                inp_device.copy_range_from_async(inp_host, static_cast<size_t>(slot) * S, static_cast<size_t>(lengths_host.data()[slot]));
+        } else {
+            // one span first..last admitted row: rows in between are unchanged (in flight) or free (not read until
+            // their own admission uploads them again)
+            const int lo = adm.slots.front(), hi = adm.slots.back();
+            inp_device.copy_range_from_async(inp_host, static_cast<size_t>(lo) * S,
+                                             static_cast<size_t>(hi - lo) * S + lengths_host.data()[hi]);
+        }
+        lengths_device.scatter_from_host(idx.data(), val.data(), idx.size());
+        new_idx_device.copy_range_from_async(staging, 0, adm.slots.size());
+        pages.maybe_flush_changes();
+        return static_cast<int>(adm.slots.size());
+    };
+
+    long long step = 0;
+    int n_new = admit(0);
+    {
+        Range r("forward");
+        forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
+    }
+    while (true) {
+        // A. result(step) starts travelling as soon as forward(step) is done
+        result_host.copy_range_from_async(result_device, 0, n_batch_size);
+        mli::mem::record_marker(marker.m);
+
+        // B. pages for forward(step + 1): every in-flight row has exactly one token in flight, so it needs room for
+        //    tokens + 2 positions (the reference's rule with the in-flight token counted); a dry pool preempts from
+        //    the tail of the admission list, and the victim's device length is zeroed before forward(step + 1)
+        {
+            Range r("allocate_or_free_memory_blocks_if_needed");
+            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2);
+            idx.clear();
+            val.clear();
+            for (int b = 0; b < B; ++b) {
+                if (first_step[b] >= 0 && !processing_storage.batch_id_processing(b)) {  // preempted just now
+                    first_step[b] = -1;
+                    lengths_host.data()[b] = 0;
+                    idx.push_back(b);
+                    val.push_back(0);
+                }
+            }
+            if (!idx.empty()) lengths_device.scatter_from_host(idx.data(), val.data(), idx.size());
+        }
+
+        // C. + D. admission into the slots known to be free, then the next forward
+        n_new = admit(step + 1);
+        {
+            Range r("forward");
+            forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
+        }
+
+        // E. result(step)
+        std::vector<int> finished;
+        {
+            Range r("process_decoder_result");
+            mli::mem::wait_marker(marker.m);
+            const int* tokens = result_host.data();
+            int appended = 0;
+            for (int b = 0; b < B; ++b) {
+                if (first_step[b] < 0 || first_step[b] > step) continue;  // empty, or admitted after forward(step)
+                const int tok = tokens[b];
+                if (tok == EMPTY_ROW_TOKEN_ID) throw std::runtime_error("pipelined engine: in-flight row reported empty");
+                IdTokensPair& item = processing_storage.get_token(b);
+                append_token_to_id_string_pair(item, tok);
+                ++appended;
+                if (tok == EOF_TOKEN_ID || static_cast<int>(item.second.size()) >= S) {
+                    processing_storage.move_to_finished(b, item_storage);
+                    first_step[b] = -1;
+                    lengths_host.data()[b] = 0;  // the decoder zeroed the device length already
+                    finished.push_back(b);
+                }
+            }
+            get_global_throughput_counter().add_record_if_recording(appended);
+        }
+        // pages of finished rows go back; with rounds = 1 and the tokens just appended this asks for exactly what B
+        // already provided, so nothing grows here
+        if (!finished.empty())
+            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/1);
+        ++step;
+        if (is_done(item_storage, processing_storage)) break;
+    }
+    mli::runtime::synchronize();  // forward(step) is still in flight (every row empty): drain before the tensors go
+    return step + 1;
+}
+
+void start_paged_attention_inference_engine_pipelined(const TensorFloat& emb_table, const TensorFloat& pos_table,
+                                                      ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                                      MemoryBlockManager& memory_block_manager,
+                                                      PagedAttentionsManager& paged_attention_manager,
+                                                      PagedAttentionInferenceModel& inference_model,
+                                                      size_t n_batch_size, size_t n_sequence) {
+    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
+                               n_batch_size, n_sequence,
+                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
+                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                                           paged_attention_manager.get_page_table_device());
+                               });
+    get_global_throughput_counter().print_throughput();
+}
+
+void start_paged_attention_cublas_inference_engine_pipelined(
+    const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
+    ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
+    PagedAttentionsManager& paged_attention_manager, PagedAttentionCublasInferenceModel& inference_model,
+    size_t n_batch_size, size_t n_sequence) {
+    GemmHandle handle;
+    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
+                               n_batch_size, n_sequence,
+                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
+                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                                           paged_attention_manager.get_page_table_device(), handle);
+                               });
+    get_global_throughput_counter().print_throughput();
+}
+
+void start_paged_attention_bf16_inference_engine_pipelined(
+    const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
+    ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
+    PagedAttentionsManager& paged_attention_manager, PagedAttentionBf16InferenceModel& inference_model,
+    size_t n_batch_size, size_t n_sequence) {
+    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
+                               n_batch_size, n_sequence,
+                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
+                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                                           paged_attention_manager.get_page_table_device());
+                               });
+    get_global_throughput_counter().print_throughput();
+}

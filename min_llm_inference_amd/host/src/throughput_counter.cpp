@@ -30,7 +30,13 @@ void ThroughputCounter::print_throughput() {
               << ", throughput: " << (s > 0 ? total_tokens_ / s : 0.0) << std::endl;
 }
 
+namespace {
+thread_local ThroughputCounter* t_counter = nullptr;
+}
+
+void set_thread_throughput_counter(ThroughputCounter* counter) { t_counter = counter; }
+
 ThroughputCounter& get_global_throughput_counter() {
     static ThroughputCounter counter;
-    return counter;
+    return t_counter ? *t_counter : counter;
 }

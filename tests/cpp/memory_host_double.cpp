@@ -48,6 +48,18 @@ void scatter8(Block* dst, const long long* index, const unsigned long long* valu
         static_cast<unsigned long long*>(dst->ptr)[index[i]] = value[i];
     }
 }
+void scatter4(Block* dst, const long long* index, const unsigned int* value, std::size_t n) {
+    for (std::size_t i = 0; i < n; ++i) {
+        if (static_cast<std::size_t>(index[i]) * 4 + 4 > dst->bytes) throw std::runtime_error("scatter out of range");
+        static_cast<unsigned int*>(dst->ptr)[index[i]] = value[i];
+    }
+}
+void copy_async(Block* dst, const Block* src, std::size_t off, std::size_t bytes) { copy(dst, src, off, bytes); }
+struct Marker {};
+Marker* create_marker() { return new Marker; }
+void destroy_marker(Marker* m) noexcept { delete m; }
+void record_marker(Marker*) {}
+void wait_marker(Marker*) {}
 Space space_of(const Block* b) { return b->space; }
 Mode mode_of(const Block* b) { return b->mode; }
 std::size_t size_of(const Block* b) { return b->bytes; }

@@ -13,12 +13,14 @@ from engine_sim import make_items, make_model, run_cpu_engine
 pytestmark = pytest.mark.gpu
 
 
-def _run(kind, model, items, B, S, n_blocks=0, rounds=1, quirk=False):
+def _run(kind, model, items, B, S, n_blocks=0, rounds=1, quirk=False, pipelined=False):
     from min_llm_inference_amd import engine as eng
     D = model["wk"].shape[0]
     V = model["emb_table"].shape[0]
     e = eng.Engine(kind, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
                    n_blocks=n_blocks, n_forward_rounds=rounds, reference_length_reset_quirk=quirk)
+    if pipelined:
+        e.set_pipelined()
     for item_id, toks in items:
         e.add_item(item_id, toks)
     st = e.run()
@@ -115,3 +117,72 @@ def test_bf16_engine_matches_cpu_engine_on_bf16_rounded_state(oracle, mli, dev):
         assert (native[item_id][:len(toks)] == toks).all()
         same += len(native[item_id]) == len(cpu[item_id]) and bool((native[item_id] == cpu[item_id]).all())
     assert same >= 0.9 * len(items), same
+
+
+def test_two_engines_on_private_streams_overlap_safely(oracle, mli, dev):
+    """Two engines in one process, one host thread each, each on its own non-blocking stream (so their kernels and
+    copies interleave on the GPU): per-engine scratch, counters and stream-ordered copies must keep every item's
+    token stream equal to the single-engine / CPU result."""
+    import threading
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 16, 4096 // 16, 512, 1024      # S = 256, D = 512: split-sequence scratch in use
+    model = make_model(51, V, S, D)
+    items = make_items(52, 48, 1, 100)
+    cpu, _ = run_cpu_engine(oracle, model, items, B, S)
+    engines, outs, errs = [], [None, None], []
+    for r in range(2):
+        e = eng.Engine(eng.PAGED_GEMM, B // 2, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"],
+                       model["wv"], n_blocks=(B // 2) * 10)
+        e.use_private_stream()
+        for item_id, toks in items[r::2]:
+            e.add_item(item_id, toks)
+        engines.append(e)
+
+    def drive(r):
+        try:
+            st = engines[r].run()
+            assert st.finished == len(items[r::2]) and st.total_tokens > 0
+            outs[r] = dict(engines[r].finished())
+        except Exception as ex:  # surfaced below: an exception in a thread would otherwise pass silently
+            errs.append(ex)
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    got = {**outs[0], **outs[1]}
+    for item_id, _ in items:
+        assert len(got[item_id]) == len(cpu[item_id]) and (got[item_id] == cpu[item_id]).all(), item_id
+    for e in engines:
+        e.close()
+
+
+@pytest.mark.parametrize("kind_name,n_blocks_per_slot", [("PAGED", 4), ("PAGED_GEMM", 4), ("PAGED_GEMM", 8), ("PAGED", 5)])
+def test_pipelined_engine_same_tokens_as_cpu_engine(oracle, mli, dev, kind_name, n_blocks_per_slot):
+    """The pipelined loop (host one step behind the GPU, per-slot device updates, one-step-late refill, in-flight
+    token of a preempted row dropped and regenerated) must leave every item's token stream unchanged; the tight pools
+    force page growth and preemption while tokens are in flight."""
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 16, 128, 64, 1024
+    model = make_model(53, V, S, D)
+    items = make_items(54, 70, 1, 60)
+    cpu, _ = run_cpu_engine(oracle, model, items, B, S)
+    st, got = _run(getattr(eng, kind_name), model, items, B, S, n_blocks=n_blocks_per_slot * B, pipelined=True)
+    assert st.finished == len(items) and st.waiting == 0 and st.in_flight == 0
+    for item_id, _ in items:
+        assert len(got[item_id]) == len(cpu[item_id]) and (got[item_id] == cpu[item_id]).all(), item_id
+    assert st.total_tokens == sum(len(cpu[i]) - len(t) for i, t in items)   # a dropped in-flight token is appended once, after regeneration
+
+
+def test_pipelined_engine_large_batch_with_preemption(mli, dev):
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 64, 160, 256, 1024
+    model = make_model(55, V, S, D)
+    items = make_items(56, 3 * B, 1, 63)
+    _, seq = _run(eng.PAGED_GEMM, model, items, B, S, n_blocks=4 * B)
+    st, pip = _run(eng.PAGED_GEMM, model, items, B, S, n_blocks=4 * B, pipelined=True)
+    assert st.finished == len(items)
+    for item_id, _ in items:
+        assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), item_id
