@@ -3,6 +3,7 @@
 // min_llm_inference_amd/host/include and linked with libmli_hip.so -- no HIP header, no Python.
 // Pass criterion = the reference's: every item finishes (finish_count == n_items); plus contiguous, paged and
 // paged-"cublas" engines must agree token for token.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -12,6 +13,7 @@
 #include "constants.h"
 #include "inference_model.h"
 #include "inferencer.h"
+#include "pipelined_engine.h"
 #include "throughput_counter.h"
 
 static std::mt19937 rng(4711);
@@ -93,9 +95,60 @@ int main() {
         failures += storage.finish_count() != n_items;
         gemm = collect(storage);
     }
+    // 4. pipelined loop (extension), tight pool: preemption while tokens are in flight
+    std::map<int, std::vector<int>> pipelined;
+    {
+        ItemStorage storage;
+        ProcessingStorage processing;
+        for (const auto& it : items) storage.add_new_item(IdTokensPair(it));
+        MemoryBlockManager pool(DEFAULT_INIT_NUM_BLOCKS * B, PAGE_BLOCK_SIZE * 3 * D);
+        PagedAttentionsManager pages(B, S, D);
+        PagedAttentionCublasInferenceModel model(PagedAttentionCublasLayer(clone(wk), clone(wq), clone(wv), B, D, S),
+                                                 PagedEncoderLayer(), PagedCublasDecoderLayer(B, V), B, S, D, 1);
+        start_paged_attention_cublas_inference_engine_pipelined(emb, pos, storage, processing, pool, pages, model, B, S);
+        std::printf("pipelined paged gemm engine: finished %d of %d\n", storage.finish_count(), n_items);
+        failures += storage.finish_count() != n_items;
+        pipelined = collect(storage);
+    }
+    // 5. bf16 pages (extension): finishes, prompts intact (tokens differ from fp32 by design)
+    {
+        ItemStorage storage;
+        ProcessingStorage processing;
+        for (const auto& it : items) storage.add_new_item(IdTokensPair(it));
+        MemoryBlockManager pool(DEFAULT_INIT_NUM_BLOCKS * B, bf16_page_block_floats(D));
+        PagedAttentionsManager pages(B, S, D);
+        TensorFloat hk({D, D}, DeviceType::HOST), hq({D, D}, DeviceType::HOST), hv({D, D}, DeviceType::HOST);
+        hk.copy_from(wk); hq.copy_from(wq); hv.copy_from(wv);
+        PagedAttentionBf16InferenceModel model(
+            PagedAttentionBf16Layer(make_device_bf16(hk.data(), {D, D}), make_device_bf16(hq.data(), {D, D}),
+                                    make_device_bf16(hv.data(), {D, D}), B, D, S), B, S, D, V, 1);
+        start_paged_attention_bf16_inference_engine(emb, pos, storage, processing, pool, pages, model, B, S, 1);
+        std::printf("bf16 paged engine: finished %d of %d\n", storage.finish_count(), n_items);
+        failures += storage.finish_count() != n_items;
+        int broken = 0;
+        for (const auto& kv : collect(storage)) {
+            const std::vector<int>& prompt = items[kv.first].second;
+            if (kv.second.size() <= prompt.size() || !std::equal(prompt.begin(), prompt.end(), kv.second.begin())) ++broken;
+        }
+        std::printf("bf16 items with a damaged prompt: %d\n", broken);
+        failures += broken != 0;
+    }
+    // 6. the async-allocation Tensor flavour (reference tensor.hpp:182-269): allocate, copy H2D and back on the
+    //    transfer stream, data() waits for readiness
+    {
+        Tensor<float> h({1 << 16}, DeviceType::HOST, TensorDataType::ASYNC_ALLOCATE), back({1 << 16}, DeviceType::HOST, TensorDataType::ASYNC_ALLOCATE);
+        Tensor<float> d({1 << 16}, DeviceType::DEVICE, TensorDataType::ASYNC_ALLOCATE);
+        for (size_t i = 0; i < h.get_total_size(); ++i) h.data()[i] = static_cast<float>(i) * 0.5f;
+        d.copy_from(h);
+        back.copy_from(d);
+        int bad = 0;
+        for (size_t i = 0; i < back.get_total_size(); ++i) bad += back.data()[i] != static_cast<float>(i) * 0.5f;
+        std::printf("async-allocation tensor round trip: %d mismatches\n", bad);
+        failures += bad != 0;
+    }
     int mismatched = 0;
     for (const auto& kv : naive)
-        if (paged[kv.first] != kv.second || gemm[kv.first] != kv.second) ++mismatched;
+        if (paged[kv.first] != kv.second || gemm[kv.first] != kv.second || pipelined[kv.first] != kv.second) ++mismatched;
     std::printf("items whose tokens differ between engines: %d\n", mismatched);
     failures += mismatched != 0;
     std::printf("%s\n", failures ? "FAILED" : "ALL ENGINES AGREE");

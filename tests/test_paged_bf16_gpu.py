@@ -12,7 +12,7 @@ from helpers import assert_close, assert_equal, bf16_bits, bf16_round, paged_cas
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(61, 37, 128, 64), (62, 24, 256, 512), (63, 6, 1024, 256), (64, 3, 4096, 512), (65, 5, 64, 2048), (66, 9, 96, 520), (67, 4, 128, 4096)]
+SHAPES = [(61, 37, 128, 64), (62, 24, 256, 512), (63, 6, 1024, 256), (64, 3, 4096, 512), (65, 5, 64, 2048), (66, 9, 96, 520), (67, 2, 48, 2560)]
 
 
 def _case(oracle, dev, seed, B, S, D, zero_every=None):
