@@ -31,8 +31,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // BF16 (paged modes only): x, W and the K/V outputs are bfloat16, q and the accumulation fp32.  Operands are
 // widened to fp32 while they are staged into LDS, so the product is still the exact fp32 MFMA chain
 // (bf16 x bf16 products are exact in fp32); a native v_mfma_f32_32x32x16_bf16 tile is the next step.
-template <int MODE, bool BT, bool VEC4, bool BF16 = false>
+// MT: 32-row sub-tiles per wave along M.  MT = 2 (128x64 workgroup tile) shares every weight fragment between two
+// MFMAs with independent accumulators: 1.5 instead of 2 LDS fragment reads per MFMA and half the barriers per flop.
+template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup
+    constexpr int LDA = BM + 1;
     __shared__ float As[BK * LDA];
     constexpr int LDBX = BT ? LDBT : LDB;
     __shared__ __align__(16) float Bs[BK * LDBX];
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     }
 
     const int tid = threadIdx.x;
-    if (tid < BM) {
+    if (tid < BM) {  // BM <= 128 < 256 threads
         RowDesc r = resolve_row<MODE, BF16>(g, m0 + tid, z, out_id);
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * 32;
+    const int wm = (wave >> 1) * 32 * MT;
     const int wn = (wave & 1) * 32;
 
     // global -> register staging coordinates
@@ -75,12 +79,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     //   B^T tile (BT): rows are n, float4 along k -- same shape as the A tile
     const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
     const int b_row = tid >> 4, b_nq = (tid & 15) * 4;
-    float4 a_reg[2], b_reg[2];
+    constexpr int AP = 2 * MT;  // A staging passes of 32 rows
+    float4 a_reg[AP], b_reg[2];
+    // this thread's source rows, kept in registers: re-reading them from LDS every tile put a wait-for-LDS and a
+    // branch per pass into every k step
+    const float* a_src[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) a_src[p] = a_ptr[a_row + p * 32];
 
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float* ap = a_ptr[a_row + p * 32];
+        for (int p = 0; p < AP; ++p) {
+            const float* ap = a_src[p];
             const int k = k0 + a_kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ap != nullptr) {
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
     auto store_tile = [&]() {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < AP; ++p) {
             const int m = a_row + p * 32;
             As[(a_kq + 0) * LDA + m] = a_reg[p].x;
             As[(a_kq + 1) * LDA + m] = a_reg[p].y;
@@ -158,9 +168,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
     const int lk = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
@@ -173,12 +185,15 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         if (t + 1 < nk) load_tile((t + 1) * BK);  // in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[(kk + lk) * LDA + wm + li];
             const float b = Bs[(kk + lk) * LDBX + wn + li];
-            // the K output of the contiguous layout is stored transposed: swap operands so
-            // that the sequence index lands on the lane (coalesced kt_cache stores)
-            if (transposed_out) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a = As[(kk + lk) * LDA + wm + mt * 32 + li];
+                // the K output of the contiguous layout is stored transposed: swap operands so
+                // that the sequence index lands on the lane (coalesced kt_cache stores)
+                if (transposed_out) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[mt], 0, 0, 0);
+                else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (t + 1 < nk) {
@@ -190,20 +205,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     // epilogue: accumulator register r of lane l is tile element
     //   (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (transposed_out) {
-            const int n = n0 + wn + trow;   // rows of the swapped product run along N
-            const int mi = wm + li;
-            float* op = o_ptr[mi];
-            if (op != nullptr && n < g.N) op[(int64_t)n * o_stride] = acc[r];
-        } else {
-            const int mi = wm + trow;
-            const int n = n0 + wn + li;
-            float* op = o_ptr[mi];
-            if (op != nullptr && n < g.N) {
-                if (BF16 && out_id != 1) reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[r]);
-                else op[n] = acc[r];
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int trow = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (transposed_out) {
+                const int n = n0 + wn + trow;   // rows of the swapped product run along N
+                const int mi = wm + mt * 32 + li;
+                float* op = o_ptr[mi];
+                if (op != nullptr && n < g.N) op[(int64_t)n * o_stride] = acc[mt][r];
+            } else {
+                const int mi = wm + mt * 32 + trow;
+                const int n = n0 + wn + li;
+                float* op = o_ptr[mi];
+                if (op != nullptr && n < g.N) {
+                    if (BF16 && out_id != 1) reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[mt][r]);
+                    else op[n] = acc[mt][r];
+                }
             }
         }
     }
@@ -211,10 +229,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles
+void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v != 0; }
+
+// rows = live extent of the M dimension (per z-slice)
 template <int MODE, bool BT>
-static int launch_gemm(const GemmArgs& g, int m_tiles, int z, bool vec4, hipStream_t st) {
-    if (g.N <= 0 || g.K <= 0 || m_tiles <= 0 || z <= 0) return MLI_ERR_BAD_ARG;
-    dim3 grid(ceil_div_i(g.N, BN) * g.n_out, m_tiles, z);
+static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_t st) {
+    if (g.N <= 0 || g.K <= 0 || rows <= 0 || z <= 0) return MLI_ERR_BAD_ARG;
+    const int tiles_x = ceil_div_i(g.N, BN) * g.n_out;
+    // 128-row tiles when they still fill the chip (>= 2 workgroups per CU) -- decode projection / logits of a large
+    // batch; the prefill fill keeps 64-row tiles (a new row's prompt rarely fills 128 rows)
+    constexpr bool kTallOk = MODE == kPagedLatest || MODE == kNaiveLatest || MODE == kPlain;
+    if (kTallOk && vec4 && g_gemm_tall_tiles && (int64_t)tiles_x * ceil_div_i(rows, 128) * z >= 512) {
+        dim3 grid(tiles_x, ceil_div_i(rows, 128), z);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 2>), grid, dim3(kGemmThreads), 0, st, g);
+        return launch_status();
+    }
+    dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
     if (vec4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true>), grid, dim3(kGemmThreads), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, false>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();
@@ -230,7 +261,7 @@ int launch_latest_naive(const float* inp, const int* lengths, const float* wk, c
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
     const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wq) && aligned16(wv);
-    return launch_gemm<kNaiveLatest, false>(g, ceil_div_i(B, BM), 1, vec4, st);
+    return launch_gemm<kNaiveLatest, false>(g, B, 1, vec4, st);
 }
 
 int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, const float* wk, const float* wv,
@@ -244,7 +275,7 @@ int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, 
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
     const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wv);
-    return launch_gemm<kNaiveFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
+    return launch_gemm<kNaiveFill, false>(g, S, n_new, vec4, st);
 }
 
 int launch_latest_paged(float* const* page_table, const int* lengths, const float* wk, const float* wq,
@@ -257,7 +288,7 @@ int launch_latest_paged(float* const* page_table, const int* lengths, const floa
     g.page_table = page_table; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
     const bool vec4 = aligned16(wk) && aligned16(wq) && aligned16(wv);
-    return launch_gemm<kPagedLatest, false>(g, ceil_div_i(B, BM), 1, vec4, st);
+    return launch_gemm<kPagedLatest, false>(g, B, 1, vec4, st);
 }
 
 int launch_fill_paged(float* const* page_table, const int* new_idx, const int* lengths, const float* wk,
@@ -271,7 +302,7 @@ int launch_fill_paged(float* const* page_table, const int* new_idx, const int* l
     g.page_table = page_table; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
     const bool vec4 = aligned16(wk) && aligned16(wv);
-    return launch_gemm<kPagedFill, false>(g, ceil_div_i(S, BM), n_new, vec4, st);
+    return launch_gemm<kPagedFill, false>(g, S, n_new, vec4, st);
 }
 
 // bf16 tile engine: 1 = native v_mfma_f32_32x32x16_bf16 (proj_gemm_bf16.hip, default), 0 = operands widened to
@@ -323,7 +354,7 @@ int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int 
     g.M = M; g.N = N; g.K = K;
     g.a_plain = A; g.c_plain = C; g.lda = K; g.ldc = N;
     const bool vec4 = K % 4 == 0 && aligned16(A) && aligned16(Bt);
-    return launch_gemm<kPlain, true>(g, ceil_div_i(M, BM), 1, vec4, st);
+    return launch_gemm<kPlain, true>(g, M, 1, vec4, st);
 }
 
 }  // namespace mli
