@@ -57,6 +57,8 @@ class Workload:
         rng = np.random.default_rng(seed)
         self.dev = dev
         lengths = rng.integers(S // 4, 3 * S // 4 + 1, size=B).astype(np.int32)
+        if os.environ.get("MLI_BENCH_LENGTHS") == "uniform":  # diagnostic: no length variation between rows
+            lengths[:] = S // 2
         assert int(lengths.max()) + headroom + 2 < S
         self.lengths_host = lengths
         self.lengths = torch.from_numpy(lengths).to(dev)

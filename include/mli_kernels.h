@@ -232,6 +232,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
  *                      launches as the reference (qkt, softmax_in_place_with_lengths, softmax_v), -1 (default) =
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
+ *   "fill_compact"     1 (default) = the prefill GEMM runs over the flat list of (new row, token) pairs, 0 = one tile
+ *                      grid per new row (the reference's decomposition); bit-identical results
  *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the fp32 decode projection / logits GEMM when the
  *                      grid still fills the chip, 0 = always 64x64
  *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened

@@ -24,6 +24,7 @@ void set_bf16_native_mfma(int v);  // proj_gemm.hip
 void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
 void set_gemm_tall_tiles(int v);
+void set_fill_compact(int v);
 
 // Tuning knobs (mli_tune): 0 = use the built-in heuristic / default.
 static int g_chunk_tokens = 0;
@@ -653,6 +654,8 @@ int mli_tune(const char* key, int value) {
         mli::g_chunk_tokens = value;
     } else if (k == "nt_loads") {
         mli::g_nt_loads = value != 0;
+    } else if (k == "fill_compact") {
+        mli::set_fill_compact(value);
     } else if (k == "gemm_tall_tiles") {
         mli::set_gemm_tall_tiles(value);
     } else if (k == "flash_variant") {

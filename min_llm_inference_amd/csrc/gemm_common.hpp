@@ -2,6 +2,8 @@
 // the per-row source / destination resolution (page-table lookups happen here, once per workgroup).
 #pragma once
 
+#include <type_traits>
+
 #include "device_common.hpp"
 
 namespace mli {
@@ -32,7 +34,79 @@ struct GemmArgs {
     const int* lengths;
     const int* new_batch_idx;    // fill
     int B, S;
+    int n_new;       // fill: number of live entries of new_batch_idx
+    int compact;     // fill: 1 = the M dimension is the flat list of all (new row, token) pairs (see FillIndex)
 };
+
+// Prefill over a FLAT row list.  A new row's prompt rarely fills a 64-row tile (the reference's workload: prompts of
+// 1..64 tokens), so a grid of (row, tile-of-the-row) workgroups multiplies mostly padding.  Instead every
+// (new row z, token s < L_z) pair gets one flat index; a workgroup takes 64 consecutive pairs, whichever rows they
+// belong to.  The host does not know the lengths (they live on the device), so the grid keeps its upper bound and
+// every workgroup rebuilds the prefix sums of the new rows' lengths in LDS (<= kMaxCompactRows entries, one
+// cooperative scan) and leaves when its tile starts beyond the total.
+constexpr int kMaxCompactRows = 2048;
+
+template <int ROWS>
+struct FillIndexT {
+    int prefix[ROWS + 1];  // prefix[z] = pairs before new row z; prefix[n_new] = total
+    int wave_tot[8];
+};
+using FillIndex = FillIndexT<kMaxCompactRows>;
+using NoFillIndex = FillIndexT<1>;  // placeholder of the kernels that do no prefill (zero-length arrays are not allowed)
+
+// all THREADS (a multiple of 64, <= 512) threads of the workgroup call this; returns the total number of pairs
+template <int THREADS, class FI>
+__device__ __forceinline__ int build_fill_index(const GemmArgs& g, FI& fi) {
+    const int tid = threadIdx.x;
+    const int per = (g.n_new + THREADS - 1) / THREADS;  // <= kMaxCompactRows / THREADS
+    int sum = 0;
+    int local[kMaxCompactRows / THREADS];
+#pragma unroll
+    for (int j = 0; j < kMaxCompactRows / THREADS; ++j) {
+        const int zz = tid * per + j;
+        int L = 0;
+        if (j < per && zz < g.n_new) L = min(max(g.lengths[g.new_batch_idx[zz]], 0), g.S);
+        local[j] = sum;
+        sum += L;
+    }
+    // inclusive scan of `sum` across the wave, then across the waves
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if ((tid & (kWave - 1)) >= off) incl += up;
+    }
+    if ((tid & (kWave - 1)) == kWave - 1) fi.wave_tot[tid / kWave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / kWave; ++w) {
+        if (w < tid / kWave) base += fi.wave_tot[w];
+        total += fi.wave_tot[w];
+    }
+    base += incl - sum;  // exclusive prefix of this thread's first row
+#pragma unroll
+    for (int j = 0; j < kMaxCompactRows / THREADS; ++j) {
+        const int zz = tid * per + j;
+        if (j < per && zz < g.n_new) fi.prefix[zz] = base + local[j];
+    }
+    if (tid == 0) fi.prefix[g.n_new] = total;
+    __syncthreads();
+    return total;
+}
+
+// flat pair index -> (new row z, token s); i < prefix[n_new]
+template <class FI>
+__device__ __forceinline__ void fill_index_lookup(const FI& fi, int n_new, int i, int& z, int& s) {
+    int lo = 0, hi = n_new;  // largest z with prefix[z] <= i (rows of length 0 share a prefix value: take the last)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (fi.prefix[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    z = lo;
+    s = i - fi.prefix[lo];
+}
 
 struct RowDesc {
     const float* a;  // nullptr -> row contributes zeros and is not stored
@@ -71,9 +145,10 @@ __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, 
         if (L <= 0) return r;  // empty slot: nothing read, nothing written
         s = L - 1;
     } else {
+        // fill: z = index into new_batch_idx, m = token (the compact form resolves the pair before calling)
         b = g.new_batch_idx[z];
         s = m;
-        if (s >= g.lengths[b]) return r;
+        if (s >= g.lengths[b] || s >= g.S) return r;
     }
     if (MODE == kNaiveLatest || MODE == kNaiveFill) {
         r.a = g.inp_embedding + ((int64_t)b * g.S + s) * g.K;

@@ -51,14 +51,30 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     const int out_id = g.out_id[wsel];
     const float* __restrict__ Bmat = g.w[wsel];
 
-    if (MODE == kNaiveFill || MODE == kPagedFill) {
-        // whole tile beyond the row's length: nothing to do (reference …optimized.cu:43-45)
-        if (m0 >= g.lengths[g.new_batch_idx[z]]) return;
+    constexpr bool kFill = MODE == kNaiveFill || MODE == kPagedFill;
+    __shared__ std::conditional_t<kFill, FillIndex, NoFillIndex> fill_index[1];
+    const int tid = threadIdx.x;
+    int fill_total = 0;
+    if (kFill) {
+        if (g.compact) {
+            fill_total = build_fill_index<kGemmThreads>(g, fill_index[0]);
+            if (m0 >= fill_total) return;  // workgroup-uniform
+        } else if (m0 >= g.lengths[g.new_batch_idx[z]]) {
+            return;  // whole tile beyond the row's length: nothing to do (reference …optimized.cu:43-45)
+        }
     }
 
-    const int tid = threadIdx.x;
     if (tid < BM) {  // BM <= 128 < 256 threads
-        RowDesc r = resolve_row<MODE, BF16>(g, m0 + tid, z, out_id);
+        RowDesc r{nullptr, nullptr};
+        if (kFill && g.compact) {
+            if (m0 + tid < fill_total) {
+                int zz, ss;
+                fill_index_lookup(fill_index[0], g.n_new, m0 + tid, zz, ss);
+                r = resolve_row<MODE, BF16>(g, ss, zz, out_id);
+            }
+        } else {
+            r = resolve_row<MODE, BF16>(g, m0 + tid, z, out_id);
+        }
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
     }
@@ -229,6 +245,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+static int g_fill_compact = 1;  // mli_tune "fill_compact": 0 = one tile grid per new row (the reference's decomposition)
+void set_fill_compact(int v) { g_fill_compact = v != 0; }
+int fill_compact(int n_new) { return g_fill_compact && n_new <= kMaxCompactRows ? 1 : 0; }
+
 static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v != 0; }
 
@@ -246,6 +266,7 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
         return launch_status();
     }
     dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
+    if (g.compact) grid = dim3(tiles_x, ceil_div_i(rows * z, BM), 1);  // flat (new row, token) list: upper bound
     if (vec4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true>), grid, dim3(kGemmThreads), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, false>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();
@@ -274,6 +295,7 @@ int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, 
     g.M = S; g.N = Dout; g.K = Din;
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
+    g.n_new = n_new; g.compact = fill_compact(n_new);
     const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wv);
     return launch_gemm<kNaiveFill, false>(g, S, n_new, vec4, st);
 }
@@ -301,6 +323,7 @@ int launch_fill_paged(float* const* page_table, const int* new_idx, const int* l
     g.M = S; g.N = D; g.K = D;
     g.page_table = page_table; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
+    g.n_new = n_new; g.compact = fill_compact(n_new);
     const bool vec4 = aligned16(wk) && aligned16(wv);
     return launch_gemm<kPagedFill, false>(g, S, n_new, vec4, st);
 }
@@ -341,7 +364,9 @@ int launch_fill_paged_bf16(uint16_t* const* page_table, const int* new_idx, cons
     g.M = S; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
+    g.n_new = n_new; g.compact = fill_compact(n_new);
     dim3 grid(ceil_div_i(D, BN) * 2, ceil_div_i(S, BM), n_new);
+    if (g.compact) grid = dim3(ceil_div_i(D, BN) * 2, ceil_div_i(S * n_new, BM), 1);
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<kPagedFill, false, true, true>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();
 }

@@ -18,6 +18,8 @@ constexpr int kLdaBytes = HK * 2 + 16;   // 80
 constexpr int kLdbBytes = HN * 2 + 64;   // 192
 constexpr int kHThreads = 256;
 
+int fill_compact(int n_new);  // proj_gemm.hip
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -44,12 +46,28 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     const int out_id = g.out_id[wsel];
     const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.w[wsel]);
 
-    if (MODE == kPagedFill) {
-        if (m0 >= g.lengths[g.new_batch_idx[z]]) return;  // workgroup-uniform: every lane leaves together
-    }
+    __shared__ std::conditional_t<MODE == kPagedFill, FillIndex, NoFillIndex> fill_index[1];
     const int tid = threadIdx.x;
+    int fill_total = 0;
+    if (MODE == kPagedFill) {
+        if (g.compact) {
+            fill_total = build_fill_index<kHThreads>(g, fill_index[0]);
+            if (m0 >= fill_total) return;  // workgroup-uniform: every lane leaves together
+        } else if (m0 >= g.lengths[g.new_batch_idx[z]]) {
+            return;
+        }
+    }
     if (tid < HM) {
-        RowDesc r = resolve_row<MODE, true>(g, m0 + tid, z, out_id);
+        RowDesc r{nullptr, nullptr};
+        if (MODE == kPagedFill && g.compact) {
+            if (m0 + tid < fill_total) {
+                int zz, ss;
+                fill_index_lookup(fill_index[0], g.n_new, m0 + tid, zz, ss);
+                r = resolve_row<MODE, true>(g, ss, zz, out_id);
+            }
+        } else {
+            r = resolve_row<MODE, true>(g, m0 + tid, z, out_id);
+        }
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
     }
@@ -148,7 +166,9 @@ int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_id
     g.M = S; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
+    g.n_new = n_new; g.compact = fill_compact(n_new);
     dim3 grid(ceil_div_i(D, HN) * 2, ceil_div_i(S, HM), n_new);
+    if (g.compact) grid = dim3(ceil_div_i(D, HN) * 2, ceil_div_i(S * n_new, HM), 1);
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedFill>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();
 }

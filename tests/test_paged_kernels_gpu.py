@@ -65,6 +65,23 @@ def test_fill_new_k_v_cache(oracle, mli, dev, seed, B, S, D, variant):
     assert_close(host(d["pool"]), expect, what="page pool after fill")
 
 
+@pytest.mark.parametrize("seed,B,S,D", [(28, 90, 64, 128), (29, 33, 256, 132)])
+def test_fill_flat_row_list_equals_per_row_tiles(oracle, mli, dev, seed, B, S, D):
+    """The prefill multiplies the flat list of (new row, token) pairs (default) or one tile grid per new row (the
+    reference's decomposition, mli_tune fill_compact = 0): same rows, same k order -> bit-identical pages; rows of
+    length 0 and a duplicate-free random subset of new rows included."""
+    from min_llm_inference_amd import ops
+    pools = []
+    for compact in (1, 0):
+        assert mli.mli_tune(b"fill_compact", compact) == 0
+        c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=3)
+        ops.launch_fill_new_k_v_cache_paged_attention(d["page_table"], d["new_batch_idx"], d["lengths"], d["wk"], d["wv"],
+                                                      c["n_new"], S)
+        pools.append(host(d["pool"]))
+    mli.mli_tune(b"fill_compact", 1)
+    assert_equal(pools[0], pools[1], what="page pool: flat row list vs per-row tiles")
+
+
 @pytest.mark.parametrize("variant", ["plain", "cublas"])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
 def test_get_latest_k_q_v(oracle, mli, dev, seed, B, S, D, variant):

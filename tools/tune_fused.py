@@ -17,8 +17,8 @@ alg = wl.algorithmic_bytes(wl.lengths_host)
 print(f"workload {name} {dtype}: step attention bytes {alg['step']/1e9:.3f} GB")
 scan = [v for k, v in wl.kernels().items() if k.startswith("fused_decode_scan")][0]
 for rnd in range(3):
-    for variant in (0, 3):
-        for ct in (0,):
+    for variant in (0,):
+        for ct in (256, 512, 1024):
             lib.mli_tune(b"flash_variant", variant)
             lib.mli_tune(b"chunk_tokens", ct)
             t = bench.time_kernel(scan, 20)
