@@ -234,6 +234,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
  *   "fill_compact"     1 (default) = the prefill GEMM runs over the flat list of (new row, token) pairs, 0 = one tile
  *                      grid per new row (the reference's decomposition); bit-identical results
+ *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
+ *                      (zeros for the empty ones); bit-identical results
  *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the fp32 decode projection / logits GEMM when the
  *                      grid still fills the chip, 0 = always 64x64
  *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened

@@ -21,6 +21,7 @@ constexpr int kFuThreads = 256;
 constexpr int kFuWaves = kFuThreads / kWave;
 
 int sv_chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip
+int tuned_chunk_tokens();
 size_t stats_region_bytes_for(int B, int S);
 int nt_loads_enabled();
 
@@ -359,7 +360,9 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     // variant 3: single-wave workgroups of 128 tokens -- every wave is its own scheduling unit, no LDS merge,
     // no barrier; the hardware dispatcher does the load balancing
     const bool solo = g_flash_variant == 3 && S > 128 && !dsplit;
-    const int ct = solo ? 128 : sv_chunk_tokens_for(B, S);
+    // short sequences with a full batch: one workgroup per row (no partials, no combine launch) beats two 64-token
+    // chunks (README workload, S = 128: 200 vs 209 us)
+    const int ct = solo ? 128 : (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : sv_chunk_tokens_for(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     const size_t stats_bytes = stats_region_bytes_for(B, S);

@@ -25,6 +25,7 @@ void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
 void set_gemm_tall_tiles(int v);
 void set_fill_compact(int v);
+void set_latest_compact(int v);
 
 // Tuning knobs (mli_tune): 0 = use the built-in heuristic / default.
 static int g_chunk_tokens = 0;
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
 int chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence); }
 int sv_chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence, kSvUnits); }
 int nt_loads_enabled() { return g_nt_loads; }
+int tuned_chunk_tokens() { return g_chunk_tokens; }
 
 int launch_softmax_v_combine(const float* partial, const int* lengths, float* out, int B, int S, int D, int ct,
                              int nchunk, hipStream_t st) {
@@ -654,6 +656,8 @@ int mli_tune(const char* key, int value) {
         mli::g_chunk_tokens = value;
     } else if (k == "nt_loads") {
         mli::g_nt_loads = value != 0;
+    } else if (k == "latest_compact") {
+        mli::set_latest_compact(value);
     } else if (k == "fill_compact") {
         mli::set_fill_compact(value);
     } else if (k == "gemm_tall_tiles") {

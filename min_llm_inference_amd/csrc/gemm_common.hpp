@@ -35,7 +35,8 @@ struct GemmArgs {
     const int* new_batch_idx;    // fill
     int B, S;
     int n_new;       // fill: number of live entries of new_batch_idx
-    int compact;     // fill: 1 = the M dimension is the flat list of all (new row, token) pairs (see FillIndex)
+    int compact;     // 1 = the M dimension is a flat list built on the device (see FillIndex): all (new row, token)
+                     // pairs for the fill modes, the non-empty batch rows for the latest modes
 };
 
 // Prefill over a FLAT row list.  A new row's prompt rarely fills a 64-row tile (the reference's workload: prompts of
@@ -54,18 +55,25 @@ struct FillIndexT {
 using FillIndex = FillIndexT<kMaxCompactRows>;
 using NoFillIndex = FillIndexT<1>;  // placeholder of the kernels that do no prefill (zero-length arrays are not allowed)
 
+// The decode projection ("latest" modes) uses the same index with one entry per batch row, worth 1 when the row is
+// non-empty: a continuous batch that is 40 % empty slots (a dry page pool, the tail of a run) then multiplies 40 %
+// fewer rows.
 // all THREADS (a multiple of 64, <= 512) threads of the workgroup call this; returns the total number of pairs
-template <int THREADS, class FI>
+template <int THREADS, bool LATEST, class FI>
 __device__ __forceinline__ int build_fill_index(const GemmArgs& g, FI& fi) {
     const int tid = threadIdx.x;
-    const int per = (g.n_new + THREADS - 1) / THREADS;  // <= kMaxCompactRows / THREADS
+    const int n_entries = LATEST ? g.B : g.n_new;
+    const int per = (n_entries + THREADS - 1) / THREADS;  // <= kMaxCompactRows / THREADS
     int sum = 0;
     int local[kMaxCompactRows / THREADS];
 #pragma unroll
     for (int j = 0; j < kMaxCompactRows / THREADS; ++j) {
         const int zz = tid * per + j;
         int L = 0;
-        if (j < per && zz < g.n_new) L = min(max(g.lengths[g.new_batch_idx[zz]], 0), g.S);
+        if (j < per && zz < n_entries) {
+            if (LATEST) L = g.lengths[zz] > 0 ? 1 : 0;
+            else L = min(max(g.lengths[g.new_batch_idx[zz]], 0), g.S);
+        }
         local[j] = sum;
         sum += L;
     }
@@ -88,9 +96,9 @@ __device__ __forceinline__ int build_fill_index(const GemmArgs& g, FI& fi) {
 #pragma unroll
     for (int j = 0; j < kMaxCompactRows / THREADS; ++j) {
         const int zz = tid * per + j;
-        if (j < per && zz < g.n_new) fi.prefix[zz] = base + local[j];
+        if (j < per && zz < n_entries) fi.prefix[zz] = base + local[j];
     }
-    if (tid == 0) fi.prefix[g.n_new] = total;
+    if (tid == 0) fi.prefix[n_entries] = total;
     __syncthreads();
     return total;
 }

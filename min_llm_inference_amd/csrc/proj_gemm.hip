@@ -52,25 +52,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     const float* __restrict__ Bmat = g.w[wsel];
 
     constexpr bool kFill = MODE == kNaiveFill || MODE == kPagedFill;
-    __shared__ std::conditional_t<kFill, FillIndex, NoFillIndex> fill_index[1];
+    constexpr bool kLatest = MODE == kNaiveLatest || MODE == kPagedLatest;
+    __shared__ std::conditional_t<kFill || kLatest, FillIndex, NoFillIndex> fill_index[1];
     const int tid = threadIdx.x;
     int fill_total = 0;
-    if (kFill) {
+    if (kFill || kLatest) {
         if (g.compact) {
-            fill_total = build_fill_index<kGemmThreads>(g, fill_index[0]);
+            fill_total = build_fill_index<kGemmThreads, kLatest>(g, fill_index[0]);
             if (m0 >= fill_total) return;  // workgroup-uniform
-        } else if (m0 >= g.lengths[g.new_batch_idx[z]]) {
+        } else if (kFill && m0 >= g.lengths[g.new_batch_idx[z]]) {
             return;  // whole tile beyond the row's length: nothing to do (reference …optimized.cu:43-45)
         }
     }
 
     if (tid < BM) {  // BM <= 128 < 256 threads
         RowDesc r{nullptr, nullptr};
-        if (kFill && g.compact) {
+        if ((kFill || kLatest) && g.compact) {
             if (m0 + tid < fill_total) {
                 int zz, ss;
-                fill_index_lookup(fill_index[0], g.n_new, m0 + tid, zz, ss);
-                r = resolve_row<MODE, BF16>(g, ss, zz, out_id);
+                fill_index_lookup(fill_index[0], kLatest ? g.B : g.n_new, m0 + tid, zz, ss);
+                r = kLatest ? resolve_row<MODE, BF16>(g, zz, 0, out_id) : resolve_row<MODE, BF16>(g, ss, zz, out_id);
             }
         } else {
             r = resolve_row<MODE, BF16>(g, m0 + tid, z, out_id);
@@ -248,6 +249,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int g_fill_compact = 1;  // mli_tune "fill_compact": 0 = one tile grid per new row (the reference's decomposition)
 void set_fill_compact(int v) { g_fill_compact = v != 0; }
 int fill_compact(int n_new) { return g_fill_compact && n_new <= kMaxCompactRows ? 1 : 0; }
+static int g_latest_compact = 1;  // mli_tune "latest_compact": 0 = the decode projection multiplies empty rows as zeros
+void set_latest_compact(int v) { g_latest_compact = v != 0; }
+int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxCompactRows ? 1 : 0; }
 
 static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v != 0; }
@@ -266,7 +270,8 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
         return launch_status();
     }
     dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
-    if (g.compact) grid = dim3(tiles_x, ceil_div_i(rows * z, BM), 1);  // flat (new row, token) list: upper bound
+    if (g.compact && (MODE == kNaiveFill || MODE == kPagedFill))
+        grid = dim3(tiles_x, ceil_div_i(rows * z, BM), 1);  // flat (new row, token) list: upper bound
     if (vec4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true>), grid, dim3(kGemmThreads), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, false>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();
@@ -281,6 +286,7 @@ int launch_latest_naive(const float* inp, const int* lengths, const float* wk, c
     g.M = B; g.N = Dout; g.K = Din;
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
+    g.compact = latest_compact(B);
     const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wq) && aligned16(wv);
     return launch_gemm<kNaiveLatest, false>(g, B, 1, vec4, st);
 }
@@ -309,6 +315,7 @@ int launch_latest_paged(float* const* page_table, const int* lengths, const floa
     g.M = B; g.N = D; g.K = D;
     g.page_table = page_table; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
+    g.compact = latest_compact(B);
     const bool vec4 = aligned16(wk) && aligned16(wq) && aligned16(wv);
     return launch_gemm<kPagedLatest, false>(g, B, 1, vec4, st);
 }
@@ -348,6 +355,7 @@ int launch_latest_paged_bf16(uint16_t* const* page_table, const int* lengths, co
     g.M = B; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
+    g.compact = latest_compact(B);
     dim3 grid(ceil_div_i(D, BN) * 3, ceil_div_i(B, BM), 1);
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<kPagedLatest, false, true, true>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();

@@ -19,6 +19,7 @@ constexpr int kLdbBytes = HN * 2 + 64;   // 192
 constexpr int kHThreads = 256;
 
 int fill_compact(int n_new);  // proj_gemm.hip
+int latest_compact(int n_batch);
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -46,24 +47,23 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     const int out_id = g.out_id[wsel];
     const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.w[wsel]);
 
-    __shared__ std::conditional_t<MODE == kPagedFill, FillIndex, NoFillIndex> fill_index[1];
+    constexpr bool kLatest = MODE == kPagedLatest;
+    __shared__ FillIndex fill_index[1];
     const int tid = threadIdx.x;
     int fill_total = 0;
-    if (MODE == kPagedFill) {
-        if (g.compact) {
-            fill_total = build_fill_index<kHThreads>(g, fill_index[0]);
-            if (m0 >= fill_total) return;  // workgroup-uniform: every lane leaves together
-        } else if (m0 >= g.lengths[g.new_batch_idx[z]]) {
-            return;
-        }
+    if (g.compact) {
+        fill_total = build_fill_index<kHThreads, kLatest>(g, fill_index[0]);
+        if (m0 >= fill_total) return;  // workgroup-uniform: every lane leaves together
+    } else if (MODE == kPagedFill && m0 >= g.lengths[g.new_batch_idx[z]]) {
+        return;
     }
     if (tid < HM) {
         RowDesc r{nullptr, nullptr};
-        if (MODE == kPagedFill && g.compact) {
+        if (g.compact) {
             if (m0 + tid < fill_total) {
                 int zz, ss;
-                fill_index_lookup(fill_index[0], g.n_new, m0 + tid, zz, ss);
-                r = resolve_row<MODE, true>(g, ss, zz, out_id);
+                fill_index_lookup(fill_index[0], kLatest ? g.B : g.n_new, m0 + tid, zz, ss);
+                r = kLatest ? resolve_row<MODE, true>(g, zz, 0, out_id) : resolve_row<MODE, true>(g, ss, zz, out_id);
             }
         } else {
             r = resolve_row<MODE, true>(g, m0 + tid, z, out_id);
@@ -152,6 +152,7 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.M = B; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
+    g.compact = latest_compact(B);
     dim3 grid(ceil_div_i(D, HN) * 3, ceil_div_i(B, HM), 1);
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();

@@ -82,6 +82,25 @@ def test_fill_flat_row_list_equals_per_row_tiles(oracle, mli, dev, seed, B, S, D
     assert_equal(pools[0], pools[1], what="page pool: flat row list vs per-row tiles")
 
 
+@pytest.mark.parametrize("seed,B,S,D,zero_every", [(38, 300, 64, 128, 2), (39, 70, 256, 132, 3), (40, 130, 32, 64, None)])
+def test_latest_live_row_list_equals_dense_rows(oracle, mli, dev, seed, B, S, D, zero_every):
+    """The decode projection multiplies only the non-empty rows (default) or all rows with zeros for the empty ones
+    (mli_tune latest_compact = 0): bit-identical pages and q_output, empty rows' q_output untouched either way."""
+    from min_llm_inference_amd import ops
+    got = []
+    for compact in (1, 0):
+        assert mli.mli_tune(b"latest_compact", compact) == 0
+        c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=zero_every)
+        ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["q_output"], S)
+        got.append((host(d["pool"]), host(d["q_output"])))
+    mli.mli_tune(b"latest_compact", 1)
+    assert_equal(got[0][0], got[1][0], what="page pool: live-row list vs dense rows")
+    assert_equal(got[0][1], got[1][1], what="q_output: live-row list vs dense rows")
+    empty = c["lengths"] == 0
+    if empty.any():
+        assert_equal(got[0][1][empty], c["q_output"][empty], what="q_output of empty rows (untouched)")
+
+
 @pytest.mark.parametrize("variant", ["plain", "cublas"])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
 def test_get_latest_k_q_v(oracle, mli, dev, seed, B, S, D, variant):
