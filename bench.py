@@ -95,10 +95,12 @@ class Workload:
             if os.environ.get("MLI_BENCH_POOL_ORDER") == "linear":  # diagnostic: pages handed out in address order
                 order = np.arange(total)
             table = np.zeros((B, W), np.int64)
+            self.page_ids = np.full((B, W), -1, np.int64)   # which pool block backs (row, page): tests index the pool with it
             cur = 0
             base = self.pool.data_ptr()
             for b in range(B):
                 table[b, :per_row[b]] = base + self.esize * block * order[cur:cur + per_row[b]].astype(np.int64)
+                self.page_ids[b, :per_row[b]] = order[cur:cur + per_row[b]]
                 cur += per_row[b]
             self.page_table = torch.from_numpy(table).to(dev)
             self.kv_bytes_resident = self.pool.numel() * self.esize

@@ -1,0 +1,176 @@
+"""BASELINE.json's FULL sizes on the GPU (config 3: B=256, S=1024, D=256 fp32; config 4: B=1024, S=4096, D=512,
+bf16 pages) -- the state bench.py times (shuffled page pool, lengths U[S/4, 3S/4]).  The oracle still covers the
+decode step of config 3 in full and a row sample of config 4; on top of that, properties that hold at any size:
+probabilities sum to one with an exact zero tail, a row whose V rows are all equal returns that row, slots beyond a
+row's length are never read (they are NaN here), chunking and the two forms of the composition agree, and a repeated
+launch is bit-identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAGE = 16
+
+
+def _workload(name, dev, dtype):
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.Workload(name, dev, 0xC0FFEE, headroom=8, dtype=dtype)
+
+
+def _pool_view(wl):
+    return wl.pool.view(-1, PAGE, 3, wl.D)
+
+
+def _poison_dead_slots(wl):
+    """NaN into every slot at or beyond its row's length (x, K and V): nothing there may reach a result."""
+    pid = torch.from_numpy(wl.page_ids).to(wl.dev)                                  # [B, W]
+    s = (torch.arange(wl.S // PAGE, device=wl.dev)[:, None] * PAGE + torch.arange(PAGE, device=wl.dev)[None, :])
+    live = s[None, :, :] < wl.lengths[:, None, None]                                   # [B, W, 16]
+    ok = pid >= 0
+    dead = torch.ones(_pool_view(wl).shape[0], PAGE, dtype=torch.bool, device=wl.dev)
+    dead[pid[ok]] = ~live[ok]
+    _pool_view(wl)[dead] = float("nan")
+
+
+def _rows_from_pages(wl, rows, seg):
+    """[len(rows), S, D] fp32 copy of segment `seg` of the given batch rows (zeros where no page is allocated)."""
+    out = torch.zeros(len(rows), wl.S, wl.D, device=wl.dev)
+    pv = _pool_view(wl)
+    for i, b in enumerate(rows):
+        ids = wl.page_ids[b]
+        n = int((ids >= 0).sum())
+        out[i, :n * PAGE] = pv[torch.from_numpy(ids[:n]).to(wl.dev), :, seg, :].reshape(n * PAGE, wl.D).float()
+    return out
+
+
+def _check_probabilities(wl, probs):
+    L = wl.lengths
+    mask = torch.arange(wl.S, device=wl.dev)[None, :] < L[:, None]
+    assert torch.isfinite(probs).all()
+    assert (probs >= 0).all()
+    assert (probs[~mask] == 0).all(), "zero tail"
+    sums = probs.sum(dim=1)
+    assert torch.allclose(sums[L > 0], torch.ones_like(sums[L > 0]), atol=1e-4), (sums.min().item(), sums.max().item())
+
+
+@pytest.fixture(scope="module")
+def c4(dev, mli):
+    wl = _workload("c4", dev, "bf16")
+    _poison_dead_slots(wl)
+    yield wl
+    del wl
+    torch.cuda.empty_cache()
+
+
+def test_config4_step_probabilities_masking_and_oracle_sample(oracle, mli, c4):
+    from min_llm_inference_amd import ops
+    wl = c4
+    rows = list(range(0, wl.B, wl.B // 32))[:32]                      # 32 rows spread over the batch
+    x = _rows_from_pages(wl, rows, 0).cpu().numpy()
+    ops.paged_attention_bf16(wl.page_table, wl.lengths, wl.wk, wl.wq, wl.wv, wl.new_idx, wl.q_output, wl.qkt_output,
+                             wl.attention_result, 0, wl.S)
+    torch.cuda.synchronize()
+    _check_probabilities(wl, wl.qkt_output)
+    assert torch.isfinite(wl.attention_result).all() and torch.isfinite(wl.q_output).all()
+    # oracle on the sampled rows: bf16-rounded inputs, K / V as the pages hold them AFTER the step (bf16), fp32 math
+    k = _rows_from_pages(wl, rows, 1).cpu().numpy()
+    v = _rows_from_pages(wl, rows, 2).cpu().numpy()
+    L = wl.lengths_host[rows].copy()
+    for i in range(len(rows)):                                         # dead slots are NaN in the pages
+        x[i, L[i]:] = 0; k[i, L[i]:] = 0; v[i, L[i]:] = 0
+    wq = wl.wq.float().cpu().numpy()
+    q = np.stack([x[i, L[i] - 1] @ wq for i in range(len(rows))]).astype(np.float32)
+    assert_close(wl.q_output[rows].cpu().numpy(), q, what="q_output of the sampled rows")
+    kt = np.ascontiguousarray(k.transpose(0, 2, 1))
+    s = np.zeros((len(rows), wl.S), np.float32)
+    o = np.zeros((len(rows), wl.D), np.float32)
+    oracle.qkt_host(q, kt, L, s)
+    oracle.softmax_in_place_with_lengths_host(s, L)
+    oracle.softmax_v_host(s, v, o, L)
+    assert_close(wl.qkt_output[rows].cpu().numpy(), s, what="probabilities of the sampled rows")
+    assert_close(wl.attention_result[rows].cpu().numpy(), o, what="attention_result of the sampled rows")
+
+
+def test_config4_repeat_is_bit_identical_and_forms_agree(mli, c4):
+    from min_llm_inference_amd import ops
+    wl = c4
+
+    def scan():
+        ops.decode_scan_paged(wl.q_output, wl.page_table, wl.lengths, wl.qkt_output, wl.attention_result, True)
+        torch.cuda.synchronize()
+        return wl.qkt_output.clone(), wl.attention_result.clone()
+
+    p0, o0 = scan()
+    p1, o1 = scan()
+    assert torch.equal(p0, p1) and torch.equal(o0, o1), "same launch twice: bit-identical"
+    try:
+        for ct in (256, 1024):                                     # other split points, other merge trees
+            assert mli.mli_tune(b"chunk_tokens", ct) == 0
+            p, o = scan()
+            assert (p - p0).abs().max().item() <= 1e-6 and (o - o0).abs().max().item() <= 1e-5, ct
+    finally:
+        mli.mli_tune(b"chunk_tokens", 0)
+    # the three-kernel form of the same block (q.K^T, masked softmax, softmax.V)
+    ops.launch_qkt_paged_attention_bf16(wl.q_output, wl.page_table, wl.lengths, wl.qkt_output)
+    ops.launch_softmax_in_place_with_lengths(wl.qkt_output, wl.lengths)
+    ops.launch_softmax_v_paged_attention_bf16(wl.qkt_output, wl.page_table, wl.attention_result, wl.lengths)
+    torch.cuda.synchronize()
+    assert (wl.qkt_output - p0).abs().max().item() <= 1e-6
+    assert (wl.attention_result - o0).abs().max().item() <= 1e-5
+
+
+def test_config4_rows_of_equal_v_return_that_row(mli, c4):
+    """softmax weights sum to one, so a row whose live V rows all equal c gives c (bf16 c, fp32 accumulation)."""
+    from min_llm_inference_amd import ops
+    wl = c4
+    pv = _pool_view(wl)
+    c = (torch.rand(wl.B, wl.D, device=wl.dev) * 2 - 1).to(pv.dtype)
+    pid = torch.from_numpy(wl.page_ids).to(wl.dev)
+    for b0 in range(0, wl.B, 64):                                   # V segment of every allocated page of the row := c_b
+        ids = pid[b0:b0 + 64]
+        ok = ids >= 0
+        rows = torch.arange(b0, min(b0 + 64, wl.B), device=wl.dev)[:, None].expand_as(ids)[ok]
+        pv[ids[ok], :, 2, :] = c[rows][:, None, :].expand(-1, PAGE, -1)
+    ops.decode_scan_paged(wl.q_output, wl.page_table, wl.lengths, wl.qkt_output, wl.attention_result, True)
+    torch.cuda.synchronize()
+    err = (wl.attention_result - c.float()).abs().max().item()
+    assert err <= 2e-4, err
+
+
+def test_config3_full_size_step_matches_the_oracle(oracle, mli, dev):
+    from min_llm_inference_amd import ops
+    wl = _workload("c3", dev, "f32")
+    _poison_dead_slots(wl)
+    rows = list(range(wl.B))
+    x = _rows_from_pages(wl, rows, 0).cpu().numpy()
+    k = _rows_from_pages(wl, rows, 1).cpu().numpy()
+    v = _rows_from_pages(wl, rows, 2).cpu().numpy()
+    L = wl.lengths_host.copy()
+    for b in rows:
+        x[b, L[b]:] = 0; k[b, L[b]:] = 0; v[b, L[b]:] = 0
+    ops.paged_attention(wl.page_table, wl.lengths, wl.wk, wl.wq, wl.wv, wl.new_idx, wl.q_output, wl.qkt_output,
+                        wl.attention_result, 0, wl.S)
+    torch.cuda.synchronize()
+    _check_probabilities(wl, wl.qkt_output)
+    kt = np.ascontiguousarray(k.transpose(0, 2, 1))
+    q = np.zeros((wl.B, wl.D), np.float32)
+    s = np.zeros((wl.B, wl.S), np.float32)
+    o = np.zeros((wl.B, wl.D), np.float32)
+    w = [t.cpu().numpy() for t in (wl.wk, wl.wq, wl.wv)]
+    oracle.self_attention_inference_host(x, L, w[0], w[1], w[2], np.zeros((wl.B,), np.int32), kt, v, q, s, o, 0)
+    assert_close(wl.q_output.cpu().numpy(), q, what="q_output")
+    assert_close(wl.qkt_output.cpu().numpy(), s, what="probabilities")
+    assert_close(wl.attention_result.cpu().numpy(), o, what="attention_result")
+    # the K / V rows appended by the step, through the page layout
+    k_after = _rows_from_pages(wl, rows, 1).cpu().numpy()
+    v_after = _rows_from_pages(wl, rows, 2).cpu().numpy()
+    idx = np.arange(wl.B)
+    assert_close(k_after[idx, L - 1], kt[idx, :, L - 1], what="appended K rows")
+    assert_close(v_after[idx, L - 1], v[idx, L - 1], what="appended V rows")
