@@ -24,6 +24,7 @@ struct Scratch {
     size_t bytes;
 };
 Scratch attention_scratch(int n_batch, int n_sequence, int emb_dim);
+void release_attention_scratch(void* stream) noexcept;  // frees the buffers tied to a stream that is going away
 
 // roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
 void range_push(const char* name);

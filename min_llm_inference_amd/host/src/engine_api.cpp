@@ -54,7 +54,12 @@ struct mli_engine {
     bool pipelined = false;     // mli_engine_set_pipelined: run() uses the pipelined loop (pipelined_engine.h)
     void* stream = nullptr;     // private compute stream (mli_engine_use_private_stream), else the thread's
 
-    ~mli_engine() { mli::runtime::destroy_stream(stream); }
+    ~mli_engine() {
+        if (stream) {
+            mli::runtime::release_attention_scratch(stream);
+            mli::runtime::destroy_stream(stream);
+        }
+    }
 
     // every entry point runs under this: device, stream and counter of THIS engine for the calling thread
     struct Scope {

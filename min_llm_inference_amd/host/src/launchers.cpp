@@ -2,6 +2,7 @@
 // They unpack Tensor shapes exactly the way the reference launchers do, pass the calling thread's
 // compute stream, and turn a non-zero status into the reference's error behaviour (print + throw).
 #include <cassert>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -18,9 +19,19 @@
 // Split-sequence scratch, one buffer per (device, compute stream) -- kernels of two streams may run at the same
 // time --, grown on demand (never shrinks).  It lives on the host
 // side because the C ABI itself never allocates.
+namespace {
+std::mutex g_scratch_mu;
+std::map<std::pair<int, void*>, std::unique_ptr<Tensor<char>>> g_scratch;  // (device, stream)
+}  // namespace
+
+void mli::runtime::release_attention_scratch(void* stream) noexcept {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end();) it = it->first.second == stream ? g_scratch.erase(it) : std::next(it);
+}
+
 mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequence, int dim) {
-    static std::mutex mu;
-    static std::map<std::pair<int, void*>, std::unique_ptr<Tensor<char>>> per_device;  // (device, stream)
+    std::mutex& mu = g_scratch_mu;
+    auto& per_device = g_scratch;
     const size_t need = mli_attention_workspace_bytes(n_batch, n_sequence, dim);
     if (need == 0) return {nullptr, 0};
     std::lock_guard<std::mutex> lock(mu);
