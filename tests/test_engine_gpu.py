@@ -186,3 +186,28 @@ def test_pipelined_engine_large_batch_with_preemption(mli, dev):
     assert st.finished == len(items)
     for item_id, _ in items:
         assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), item_id
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_pipelined_engine_random_configurations(mli, dev, seed):
+    """Randomised shapes and pool sizes (down to pools that can hold only a few rows at once: constant preemption):
+    the pipelined loop and the sequential loop must agree item for item, and both must drain the queue."""
+    from min_llm_inference_amd import engine as eng
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(2, 40))
+    S = 16 * int(rng.integers(2, 11))
+    D = 4 * int(rng.integers(4, 40))
+    V = 1024 + int(rng.integers(0, 300))
+    n_items = int(rng.integers(1, 3 * B + 2))
+    max_prompt = max(1, min(S - 2, int(rng.integers(1, S))))
+    width = S // 16
+    n_blocks = max(width + 4, int(rng.integers(2, 8)) * B)       # always enough for one full-length row
+    kind = [eng.PAGED, eng.PAGED_GEMM][seed % 2]
+    model = make_model(2000 + seed, V, S, D)
+    items = make_items(3000 + seed, n_items, 1, max_prompt)
+    st_seq, seq = _run(kind, model, items, B, S, n_blocks=n_blocks)
+    st_pip, pip = _run(kind, model, items, B, S, n_blocks=n_blocks, pipelined=True)
+    assert st_seq.finished == n_items and st_pip.finished == n_items, (B, S, D, n_items, n_blocks)
+    assert st_seq.total_tokens == st_pip.total_tokens
+    for item_id, _ in items:
+        assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), (item_id, B, S, D, n_blocks)
