@@ -236,8 +236,9 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      grid per new row (the reference's decomposition); bit-identical results
  *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
  *                      (zeros for the empty ones); bit-identical results
- *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the fp32 decode projection / logits GEMM when the
- *                      grid still fills the chip, 0 = always 64x64
+ *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the decode projection / logits GEMM (fp32 and bf16)
+ *                      when the grid still fills the chip, 0 = always 64x64, 2 = 128x64 whenever the mode allows it
+ *                      (lets small test shapes exercise that kernel)
  *   "bf16_native_mfma" 1 (default) = v_mfma_f32_32x32x16_bf16 tile engine for the bf16 path, 0 = operands widened
  *                      to fp32 + fp32 MFMA (bit-identical to a sequential fp32 sum; differs from 1 only by the
  *                      rounding order of the fp32 accumulation) */

@@ -253,8 +253,9 @@ static int g_latest_compact = 1;  // mli_tune "latest_compact": 0 = the decode p
 void set_latest_compact(int v) { g_latest_compact = v != 0; }
 int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxCompactRows ? 1 : 0; }
 
-static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles
-void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v != 0; }
+static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
+void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v < 0 ? 0 : (v > 2 ? 2 : v); }
+bool gemm_use_tall_tiles(int64_t tall_workgroups) { return g_gemm_tall_tiles == 2 || (g_gemm_tall_tiles == 1 && tall_workgroups >= 512); }
 
 // rows = live extent of the M dimension (per z-slice)
 template <int MODE, bool BT>
@@ -264,7 +265,7 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
     // 128-row tiles when they still fill the chip (>= 2 workgroups per CU) -- decode projection / logits of a large
     // batch; the prefill fill keeps 64-row tiles (a new row's prompt rarely fills 128 rows)
     constexpr bool kTallOk = MODE == kPagedLatest || MODE == kNaiveLatest || MODE == kPlain;
-    if (kTallOk && vec4 && g_gemm_tall_tiles && (int64_t)tiles_x * ceil_div_i(rows, 128) * z >= 512) {
+    if (kTallOk && vec4 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(rows, 128) * z)) {
         dim3 grid(tiles_x, ceil_div_i(rows, 128), z);
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 2>), grid, dim3(kGemmThreads), 0, st, g);
         return launch_status();

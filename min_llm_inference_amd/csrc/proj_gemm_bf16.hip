@@ -8,18 +8,22 @@
 //     no transposing stores -- and read with ds_read_b64_tr_b16, the gfx950 transposing LDS read, which hands
 //     each lane 4 consecutive k of its column (192-byte row stride: the 4 rows of a block land on disjoint
 //     quarters of the 64 banks);
-//   * 64x64x32 tile, 2x2 waves of 32x32, register-staged prefetch of the next tile under the MFMAs.
+//   * 64x64x32 tile, 2x2 waves of 32x32, register-staged prefetch of the next tile under the MFMAs -- the
+//     latency-bound shapes (config 4: 1.6 GFLOP per launch) and the prefill;
+//   * 128x64x64 tile (MT = 2, KB = 64: each wave two 32x32 sub-tiles sharing every weight fragment, 8 MFMAs per
+//     barrier pair instead of 2) for the decode projection of a large batch at a large emb_dim, where the small
+//     tile spends its time on staging and barriers (B=1024, D=2048: 451 TFLOP/s).
 #include "gemm_common.hpp"
 
 namespace mli {
 
 constexpr int HM = 64, HN = 64, HK = 32;
-constexpr int kLdaBytes = HK * 2 + 16;   // 80
 constexpr int kLdbBytes = HN * 2 + 64;   // 192
 constexpr int kHThreads = 256;
 
 int fill_compact(int n_new);  // proj_gemm.hip
 int latest_compact(int n_batch);
+bool gemm_use_tall_tiles(int64_t tall_workgroups);
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -32,8 +36,15 @@ union Frag8 {
     s16x4_t h[2];
 };
 
-template <int MODE>
+// MT = 32-row sub-tiles per wave (rows per workgroup = 64 * MT), KB = k extent of a staged tile (32 or 64)
+template <int MODE, int MT = 1, int KB = 32>
 __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
+    constexpr int HM = 64 * MT;              // shadows the namespace-level 64
+    constexpr int HK = KB;
+    constexpr int kLdaBytes = HK * 2 + 16;   // 80 / 144: ds_read_b128 fragment reads are conflict-free
+    constexpr int AP = HM * HK / (kHThreads * 8);   // 16-byte A loads per thread and tile
+    constexpr int BP = HK * HN / (kHThreads * 8);   // 16-byte B loads per thread and tile
+    constexpr int kAThreadsPerRow = HK / 8;
     __shared__ __align__(16) unsigned char As[HM * kLdaBytes];
     __shared__ __align__(16) unsigned char Bs[HK * kLdbBytes];
     __shared__ const float* a_ptr[HM];
@@ -75,30 +86,45 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * 32;
+    const int wm = (wave >> 1) * 32 * MT;
     const int wn = (wave & 1) * 32;
 
-    // staging coordinates: one 16-byte load per thread per operand per tile
-    const int a_row = tid >> 2, a_k8 = (tid & 3) * 8;   // A: 64 rows x 4 chunks of 8 k
-    const int b_row = tid >> 3, b_n8 = (tid & 7) * 8;   // B: 32 k-rows x 8 chunks of 8 n
-    uint4 a_reg, b_reg;
+    // staging coordinates: 16-byte loads, AP + BP per thread and tile
+    const int a_row = tid / kAThreadsPerRow, a_k8 = (tid % kAThreadsPerRow) * 8;  // A: rows x chunks of 8 k
+    constexpr int kARowsPerPass = kHThreads / kAThreadsPerRow;
+    const int b_row = tid >> 3, b_n8 = (tid & 7) * 8;                            // B: 32 k-rows x 8 chunks of 8 n
+    uint4 a_reg[AP], b_reg[BP];
+    const uint16_t* a_src[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) a_src[p] = reinterpret_cast<const uint16_t*>(a_ptr[a_row + p * kARowsPerPass]);
 
     auto load_tile = [&](int k0) {
-        a_reg = make_uint4(0, 0, 0, 0);
-        b_reg = make_uint4(0, 0, 0, 0);
-        const uint16_t* ap = reinterpret_cast<const uint16_t*>(a_ptr[a_row]);
-        if (ap != nullptr && k0 + a_k8 < g.K) a_reg = *reinterpret_cast<const uint4*>(ap + k0 + a_k8);
-        const int k = k0 + b_row, n = n0 + b_n8;
-        if (k < g.K && n < g.N) b_reg = *reinterpret_cast<const uint4*>(W + (int64_t)k * g.N + n);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            a_reg[p] = make_uint4(0, 0, 0, 0);
+            if (a_src[p] != nullptr && k0 + a_k8 < g.K) a_reg[p] = *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8);
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            b_reg[p] = make_uint4(0, 0, 0, 0);
+            const int k = k0 + b_row + p * 32, n = n0 + b_n8;
+            if (k < g.K && n < g.N) b_reg[p] = *reinterpret_cast<const uint4*>(W + (int64_t)k * g.N + n);
+        }
     };
     auto store_tile = [&]() {
-        *reinterpret_cast<uint4*>(&As[a_row * kLdaBytes + a_k8 * 2]) = a_reg;
-        *reinterpret_cast<uint4*>(&Bs[b_row * kLdbBytes + b_n8 * 2]) = b_reg;
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+            *reinterpret_cast<uint4*>(&As[(a_row + p * kARowsPerPass) * kLdaBytes + a_k8 * 2]) = a_reg[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            *reinterpret_cast<uint4*>(&Bs[(b_row + p * 32) * kLdbBytes + b_n8 * 2]) = b_reg[p];
     };
 
-    f32x16_t acc;
+    f32x16_t acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     // fragment addresses (constant over the k loop)
     const int li = lane & 31, lh = lane >> 5;
@@ -116,11 +142,15 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
         if (t + 1 < nk) load_tile((t + 1) * HK);
 #pragma unroll
         for (int kk = 0; kk < HK; kk += 16) {
-            Frag8 a, b;
-            a.u = *reinterpret_cast<const uint4*>(&As[a_off + kk * 2]);
+            Frag8 b;
             b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[b_off + kk * kLdbBytes]));
             b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&Bs[b_off + (kk + 4) * kLdbBytes]));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                Frag8 a;
+                a.u = *reinterpret_cast<const uint4*>(&As[a_off + mt * 32 * kLdaBytes + kk * 2]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mt], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (t + 1 < nk) {
@@ -131,13 +161,16 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
 
     // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mi = wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int n = n0 + wn + li;
-        float* op = o_ptr[mi];
-        if (op != nullptr && n < g.N) {
-            if (out_id == 1) op[n] = acc[r];                                         // q: fp32
-            else reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[r]);            // K / V: bf16 page rows
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mi = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int n = n0 + wn + li;
+            float* op = o_ptr[mi];
+            if (op != nullptr && n < g.N) {
+                if (out_id == 1) op[n] = acc[mt][r];                                         // q: fp32
+                else reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[mt][r]);            // K / V: bf16 page rows
+            }
         }
     }
 }
@@ -153,7 +186,13 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
     g.compact = latest_compact(B);
-    dim3 grid(ceil_div_i(D, HN) * 3, ceil_div_i(B, HM), 1);
+    const int tiles_x = ceil_div_i(D, HN) * 3;
+    if (gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {  // as the fp32 kernel: >= 2 workgroups per CU
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest, 2, 64>), dim3(tiles_x, ceil_div_i(B, 128), 1),
+                           dim3(kHThreads), 0, st, g);
+        return launch_status();
+    }
+    dim3 grid(tiles_x, ceil_div_i(B, HM), 1);
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();
 }

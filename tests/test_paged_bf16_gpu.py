@@ -124,3 +124,26 @@ def test_bf16_encoder_decoder_write_bf16_embeddings(oracle, mli, dev):
         off = table[b, L // 16] + (L % 16) * 3 * D
         assert_equal(p[off:off + D], bf16_bits(emb[toks[b]] + wpe[L]), what=f"next x[{b}]")
     assert_equal(host(d_len), np.array([0, 2, 17, 34, 63], np.int32))
+
+
+@pytest.mark.parametrize("seed,B,S,D", [(68, 200, 64, 256), (69, 150, 32, 136)])
+def test_bf16_latest_tall_tiles_equal_square_tiles(oracle, mli, dev, seed, B, S, D):
+    """The 128x64x64 tile of the native bf16 MFMA kernel (large batches) against the 64x64x32 one.  Both sum the 16
+    products of an MFMA step in hardware order and the steps in k order, so the results are bit-identical."""
+    from min_llm_inference_amd import ops
+    got = []
+    try:
+        for tall in (2, 0):
+            assert mli.mli_tune(b"gemm_tall_tiles", tall) == 0
+            c, d = _case(oracle, dev, seed, B, S, D, zero_every=4)
+            ops.launch_get_latest_k_q_v_paged_attention_bf16(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"],
+                                                             d["q_output"], S)
+            got.append((host(d["pool"]), host(d["q_output"])))
+    finally:
+        mli.mli_tune(b"gemm_tall_tiles", 1)
+    assert_equal(got[0][0], got[1][0], what="bf16 page pool: 128-row vs 64-row tiles")
+    assert_equal(got[0][1], got[1][1], what="q_output: 128-row vs 64-row tiles")
+    # and against the oracle (fp32 math on bf16-rounded inputs)
+    oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
+                             c["q_output"])
+    assert_close(got[0][1], c["q_output"], thr=1e-4, what="q_output vs oracle")

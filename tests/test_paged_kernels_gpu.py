@@ -101,6 +101,23 @@ def test_latest_live_row_list_equals_dense_rows(oracle, mli, dev, seed, B, S, D,
         assert_equal(got[0][1][empty], c["q_output"][empty], what="q_output of empty rows (untouched)")
 
 
+@pytest.mark.parametrize("seed,B,S,D", [(41, 200, 64, 256), (42, 130, 32, 132)])
+def test_latest_tall_tiles_equal_square_tiles(oracle, mli, dev, seed, B, S, D):
+    """128x64 workgroup tiles (large batches) against 64x64: same rows, same k order per element -> bit-identical."""
+    from min_llm_inference_amd import ops
+    got = []
+    try:
+        for tall in (2, 0):
+            assert mli.mli_tune(b"gemm_tall_tiles", tall) == 0
+            c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=5)
+            ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["q_output"], S)
+            got.append((host(d["pool"]), host(d["q_output"])))
+    finally:
+        mli.mli_tune(b"gemm_tall_tiles", 1)
+    assert_equal(got[0][0], got[1][0], what="page pool: 128-row vs 64-row tiles")
+    assert_equal(got[0][1], got[1][1], what="q_output: 128-row vs 64-row tiles")
+
+
 @pytest.mark.parametrize("variant", ["plain", "cublas"])
 @pytest.mark.parametrize("seed,B,S,D", SHAPES)
 def test_get_latest_k_q_v(oracle, mli, dev, seed, B, S, D, variant):
