@@ -282,7 +282,9 @@ def gemm_report(wl, lengths, times):
     peak = MFMA_PEAK_TFLOPS[wl.dtype]
     return {"bound": "mfma", "flops_per_launch": flops, "avg_launch_ms": ms, "achieved": tf, "peak": peak,
             "unit": "TFLOP/s", "frac": tf / peak,
-            "note": "1.6 GFLOP per launch at B=1024, D=512: latency-bound, 2 % of the step"}
+            "note": (f"{flops / 1e9:.1f} GFLOP per launch at B={wl.B}, D={wl.D}" +
+                     (": latency-bound, 2 % of the step; the same kernels at D=2048 (bench.py --workload e1) reach "
+                      "118 TFLOP/s fp32 / 551 TFLOP/s bf16 (DESIGN.md 3.5)" if wl.D <= 512 else ""))}
 
 
 def pmc_traffic(workload, which, layout, dtype="f32"):
