@@ -153,47 +153,3 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
     mli::runtime::synchronize();  // forward(step) is still in flight (every row empty): drain before the tensors go
     return step + 1;
 }
-
-void start_paged_attention_inference_engine_pipelined(const TensorFloat& emb_table, const TensorFloat& pos_table,
-                                                      ItemStorage& item_storage, ProcessingStorage& processing_storage,
-                                                      MemoryBlockManager& memory_block_manager,
-                                                      PagedAttentionsManager& paged_attention_manager,
-                                                      PagedAttentionInferenceModel& inference_model,
-                                                      size_t n_batch_size, size_t n_sequence) {
-    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
-                               n_batch_size, n_sequence,
-                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
-                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
-                                                           paged_attention_manager.get_page_table_device());
-                               });
-    get_global_throughput_counter().print_throughput();
-}
-
-void start_paged_attention_cublas_inference_engine_pipelined(
-    const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
-    ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
-    PagedAttentionsManager& paged_attention_manager, PagedAttentionCublasInferenceModel& inference_model,
-    size_t n_batch_size, size_t n_sequence) {
-    GemmHandle handle;
-    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
-                               n_batch_size, n_sequence,
-                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
-                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
-                                                           paged_attention_manager.get_page_table_device(), handle);
-                               });
-    get_global_throughput_counter().print_throughput();
-}
-
-void start_paged_attention_bf16_inference_engine_pipelined(
-    const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
-    ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
-    PagedAttentionsManager& paged_attention_manager, PagedAttentionBf16InferenceModel& inference_model,
-    size_t n_batch_size, size_t n_sequence) {
-    run_paged_engine_pipelined(item_storage, processing_storage, memory_block_manager, paged_attention_manager,
-                               n_batch_size, n_sequence,
-                               [&](const TensorInt& inp, TensorInt& lengths, const TensorInt& new_idx, TensorInt& result, int n_new) {
-                                   inference_model.forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
-                                                           paged_attention_manager.get_page_table_device());
-                               });
-    get_global_throughput_counter().print_throughput();
-}

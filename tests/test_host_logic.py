@@ -16,3 +16,14 @@ def test_host_scheduler_cpp_suite():
     r = subprocess.run([os.path.join(cpp, "build", "host_logic_test")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
     assert r.stdout.count("[ OK ]") >= 12
+
+
+def test_pipelined_loop_logic_against_sequential_loop_cpu():
+    """tests/cpp/pipelined_logic_test.cpp: the pipelined engine loop with a fake forward over the malloc double, 40
+    random shapes / pool sizes / EOF rates, against the reference's loop order; ASan + UBSan."""
+    cpp = os.path.join(HERE, "cpp")
+    r = subprocess.run(["make", "-C", cpp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r = subprocess.run([os.path.join(cpp, "build", "pipelined_logic_test")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.stdout.count("[ OK ]") == 40
