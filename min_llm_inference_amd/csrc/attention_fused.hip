@@ -149,8 +149,9 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
         // re-assert uniformity at the point of use: `pg` went through selects on the wave index, which the compiler
         // treats as divergent and would wrap every load in a waterfall loop
         const char* upg = reinterpret_cast<const char*>(wave_uniform(reinterpret_cast<const float*>(pg)));
+        // a null page (row longer than its pages: a caller bug) gets an empty range: its loads return zeros
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(upg), 0, block_bytes, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(upg), 0, upg != nullptr ? block_bytes : 0, 0x00020000);
         const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * (int)row_bytes;
 #pragma unroll
         for (int t = 0; t < TBR; ++t)

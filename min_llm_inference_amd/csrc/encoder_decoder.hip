@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
     if (PAGED) {
         if (threadIdx.x == 0) page_sh = page_table[(int64_t)b * (S / kPage) + blockIdx.x];
         __syncthreads();
+        if (page_sh == nullptr) return;  // a caller bug (row longer than its pages): skip rather than fault the GPU
     }
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     __syncthreads();
     const int tok = tok_sh;
     if (L + 1 >= S || tok == MLI_EOF_TOKEN_ID || tok < 0) return;  // finished rows get no next embedding
+    if (PAGED && page_sh == nullptr) return;  // no page for the next position (a caller bug): skip rather than fault
     const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
     const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
     float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(kEdThreads) void clone_to_pages_kernel(
     const int s_base = blockIdx.x * kPage;
     if (s_base > last) return;
     float* page = page_table[(int64_t)b * (S / kPage) + blockIdx.x];
+    if (page == nullptr) return;
     for (int idx = threadIdx.x; idx < kPage * D; idx += kEdThreads) {
         const int t = idx / D, d = idx % D;
         const int s = s_base + t;

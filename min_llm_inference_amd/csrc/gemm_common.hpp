@@ -169,6 +169,7 @@ __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, 
         }
     } else {
         float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
+        if (page == nullptr) return r;  // row longer than its pages (a caller bug): skipped, not dereferenced
         if (BF16) {  // same layout rule, 16-bit elements
             uint16_t* tok = reinterpret_cast<uint16_t*>(page) + page_row_offset(s, g.K, kSegInp);
             r.a = reinterpret_cast<const float*>(tok);

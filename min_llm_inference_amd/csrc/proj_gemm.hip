@@ -33,9 +33,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // (bf16 x bf16 products are exact in fp32); a native v_mfma_f32_32x32x16_bf16 tile is the next step.
 // MT: 32-row sub-tiles per wave along M.  MT = 2 (128x64 workgroup tile) shares every weight fragment between two
 // MFMAs with independent accumulators: 1.5 instead of 2 LDS fragment reads per MFMA and half the barriers per flop.
-template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1>
+// KQ: 32-deep k slabs staged per tile.  KQ = 4 (128 k per barrier pair) is for the latency-bound shapes -- one
+// workgroup per CU and a short reduction (the logits of config 4: 16 k-steps, each exposing a load round trip).
+template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, int KQ = 1>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup
+    constexpr int BK = 32 * KQ;   // shadows the namespace-level 32: k extent of a staged tile
     constexpr int LDA = BM + 1;
     __shared__ float As[BK * LDA];
     constexpr int LDBX = BT ? LDBT : LDB;
@@ -97,14 +100,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
     const int b_row = tid >> 4, b_nq = (tid & 15) * 4;
     constexpr int AP = 2 * MT;  // A staging passes of 32 rows
-    float4 a_reg[AP], b_reg[2];
+    float4 a_regs[KQ][AP], b_regs[KQ][2];
     // this thread's source rows, kept in registers: re-reading them from LDS every tile put a wait-for-LDS and a
     // branch per pass into every k step
     const float* a_src[AP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) a_src[p] = a_ptr[a_row + p * 32];
 
-    auto load_tile = [&](int k0) {
+    auto load_slab = [&](int k0, float4 (&a_reg)[AP], float4 (&b_reg)[2]) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const float* ap = a_src[p];
@@ -161,28 +164,36 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
             b_reg[p] = v;
         }
     };
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) load_slab(k0 + q * 32, a_regs[q], b_regs[q]);
+    };
 
-    auto store_tile = [&]() {
+    auto store_slab = [&](float* As_q, float* Bs_q, const float4 (&a_reg)[AP], const float4 (&b_reg)[2]) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const int m = a_row + p * 32;
-            As[(a_kq + 0) * LDA + m] = a_reg[p].x;
-            As[(a_kq + 1) * LDA + m] = a_reg[p].y;
-            As[(a_kq + 2) * LDA + m] = a_reg[p].z;
-            As[(a_kq + 3) * LDA + m] = a_reg[p].w;
+            As_q[(a_kq + 0) * LDA + m] = a_reg[p].x;
+            As_q[(a_kq + 1) * LDA + m] = a_reg[p].y;
+            As_q[(a_kq + 2) * LDA + m] = a_reg[p].z;
+            As_q[(a_kq + 3) * LDA + m] = a_reg[p].w;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (BT) {
                 const int n = a_row + p * 32;
-                Bs[(a_kq + 0) * LDBX + n] = b_reg[p].x;
-                Bs[(a_kq + 1) * LDBX + n] = b_reg[p].y;
-                Bs[(a_kq + 2) * LDBX + n] = b_reg[p].z;
-                Bs[(a_kq + 3) * LDBX + n] = b_reg[p].w;
+                Bs_q[(a_kq + 0) * LDBX + n] = b_reg[p].x;
+                Bs_q[(a_kq + 1) * LDBX + n] = b_reg[p].y;
+                Bs_q[(a_kq + 2) * LDBX + n] = b_reg[p].z;
+                Bs_q[(a_kq + 3) * LDBX + n] = b_reg[p].w;
             } else {
-                *reinterpret_cast<float4*>(&Bs[(b_row + p * 16) * LDBX + b_nq]) = b_reg[p];
+                *reinterpret_cast<float4*>(&Bs_q[(b_row + p * 16) * LDBX + b_nq]) = b_reg[p];
             }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) store_slab(As + q * 32 * LDA, Bs + q * 32 * LDBX, a_regs[q], b_regs[q]);
     };
 
     f32x16 acc[MT];
@@ -253,6 +264,9 @@ static int g_latest_compact = 1;  // mli_tune "latest_compact": 0 = the decode p
 void set_latest_compact(int v) { g_latest_compact = v != 0; }
 int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxCompactRows ? 1 : 0; }
 
+static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k": 0 = 32-deep staged tiles everywhere
+void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
+int deep_k_tiles_enabled() { return g_deep_k_tiles; }
 static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v < 0 ? 0 : (v > 2 ? 2 : v); }
 bool gemm_use_tall_tiles(int64_t tall_workgroups) { return g_gemm_tall_tiles == 2 || (g_gemm_tall_tiles == 1 && tall_workgroups >= 512); }
@@ -268,6 +282,13 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
     if (kTallOk && vec4 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(rows, 128) * z)) {
         dim3 grid(tiles_x, ceil_div_i(rows, 128), z);
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 2>), grid, dim3(kGemmThreads), 0, st, g);
+        return launch_status();
+    }
+    // one workgroup (or fewer) per CU and a reduction of at least 4 deep tiles: stage 128 k per barrier pair
+    constexpr bool kDeepOk = MODE == kPlain || MODE == kPagedLatest || MODE == kNaiveLatest;
+    if (kDeepOk && vec4 && g_deep_k_tiles && g.K >= 512 && (int64_t)tiles_x * ceil_div_i(rows, BM) * z <= 512) {
+        dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 1, 4>), grid, dim3(kGemmThreads), 0, st, g);
         return launch_status();
     }
     dim3 grid(tiles_x, ceil_div_i(rows, BM), z);

@@ -24,6 +24,7 @@ constexpr int kHThreads = 256;
 int fill_compact(int n_new);  // proj_gemm.hip
 int latest_compact(int n_batch);
 bool gemm_use_tall_tiles(int64_t tall_workgroups);
+int deep_k_tiles_enabled();
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -193,7 +194,12 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
         return launch_status();
     }
     dim3 grid(tiles_x, ceil_div_i(B, HM), 1);
-    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest>), grid, dim3(kHThreads), 0, st, g);
+    // Short reductions are latency-bound (config 4: 16 k-steps of 32, each exposing a global-load round trip that
+    // one workgroup per SIMD cannot hide): stage 128 k per tile instead -- 4 round trips.
+    if (D >= 256 && D <= 1024 && deep_k_tiles_enabled())
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest, 1, 128>), grid, dim3(kHThreads), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();
 }
 

@@ -19,5 +19,21 @@ lib = load_library()
 for rnd in range(3):
     for tall in (0, 1):
         lib.mli_tune(b"gemm_tall_tiles", tall)
+        lib.mli_tune(b"gemm_deep_k", tall)
         t = bench.time_kernel(fn, 200)
-        print(f"round {rnd} gemm_tall_tiles={tall}: projection {t*1e3:.1f} us = {flops/(t*1e-3)/1e12:.1f} TFLOP/s", flush=True)
+        print(f"round {rnd} gemm_tall_tiles=gemm_deep_k={tall}: projection {t*1e3:.1f} us = {flops/(t*1e-3)/1e12:.1f} TFLOP/s", flush=True)
+lib.mli_tune(b"gemm_tall_tiles", 1)
+lib.mli_tune(b"gemm_deep_k", 1)
+for compact in (0, 1, 0, 1):
+    lib.mli_tune(b"latest_compact", compact)
+    t = bench.time_kernel(fn, 200)
+    print(f"latest_compact={compact}: projection {t*1e3:.1f} us", flush=True)
+for deep in (0, 1, 0, 1):
+    lib.mli_tune(b"gemm_deep_k", deep)
+    def decoder_once():   # the decoder advances the lengths: rewind, or 200 calls run past the allocated pages
+        wl.lengths.copy_(wl.lengths0)
+        wl.decoder()
+    t = bench.time_kernel(decoder_once, 200)
+    wl.lengths.copy_(wl.lengths0)
+    t2 = bench.time_kernel(fn, 200)
+    print(f"gemm_deep_k={deep}: decoder head (logits GEMM + argmax) {t*1e3:.1f} us, projection {t2*1e3:.1f} us", flush=True)
