@@ -267,3 +267,33 @@ def test_page_table_indexing_bit_exact(oracle, mli, dev):
     scatter_rows_to_pool(expect, c["table"], rows, 2, c["v_cache"][bb, ss, :])
     assert_equal(host(d["pool"]), expect, what="page pool (bit exact)")
     assert_equal(host(d["q_output"]), c["q_output"], what="q_output (bit exact)")
+
+
+def test_null_page_inside_a_rows_length_is_skipped_not_dereferenced(oracle, mli, dev):
+    """A caller bug -- a row whose length says it needs a page the table does not have -- must not fault the GPU on
+    the composition path (projection GEMM, single-pass scan, decoder write): the row's missing page reads as zeros /
+    is not written, every other row is unaffected."""
+    import torch
+    from min_llm_inference_amd import ops
+    B, S, D = 12, 128, 64
+    c, d = _prepare(oracle, dev, 43, B, S, D, conditioned=True)
+    lengths = c["lengths"]
+    victim = int(np.argmax(lengths))                 # longest row: drop its LAST page (holds position L-1)
+    last_page = (int(lengths[victim]) - 1) // PAGE
+    table = host(d["page_table"]).copy()
+    table[victim, last_page] = 0
+    d["page_table"] = torch.from_numpy(table).to(dev)
+    ops.paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["q_output"],
+                        d["qkt_output"], d["attention_result"], 0, S)
+    emb = torch.rand(1100, D, device=dev)
+    wpe = torch.rand(S, D, device=dev)
+    score = torch.zeros(B, 1100, device=dev)
+    res = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+    ops.launch_paged_attention_decoder_multi_rounds(d["attention_result"], emb, score, wpe, d["page_table"], d["lengths"], res, 0)
+    torch.cuda.synchronize()
+    oracle.self_attention_inference_host(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"],
+                                         c["new_batch_idx"], c["kt_cache"], c["v_cache"], c["q_output"],
+                                         c["qkt_output"], c["attention_result"], 0)
+    others = [b for b in range(B) if b != victim]
+    assert_close(host(d["attention_result"])[others], c["attention_result"][others], what="rows with all their pages")
+    assert np.isfinite(host(d["attention_result"])).all()
