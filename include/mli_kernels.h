@@ -236,7 +236,7 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      grid per new row (the reference's decomposition); bit-identical results
  *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
  *                      (zeros for the empty ones); bit-identical results
- *   "gemm_deep_k"      1 (default) = latency-bound GEMM shapes stage 128 k per tile, 0 = 32 everywhere
+ *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
  *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the decode projection / logits GEMM (fp32 and bf16)
  *                      when the grid still fills the chip, 0 = always 64x64, 2 = 128x64 whenever the mode allows it
  *                      (lets small test shapes exercise that kernel)

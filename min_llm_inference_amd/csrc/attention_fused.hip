@@ -163,13 +163,14 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     constexpr int PSTEP = DS ? 1 : WAVES;
     const int p_first = DS ? 0 : wave;
     const char* page = p_first < npages ? page_ptr(p_first) : nullptr;
-    if (page != nullptr) {
+    if (p_first < npages) {  // (not "page != nullptr": a null table entry is a page too -- it reads as zeros)
         issue(std::integral_constant<int, 0>{}, page);
         issue(std::integral_constant<int, 1>{}, page);
         issue(std::integral_constant<int, 2>{}, page);
     }
     for (int pi = p_first; pi < npages; pi += PSTEP) {
-        const char* next = pi + PSTEP < npages ? page_ptr(pi + PSTEP) : nullptr;
+        const bool has_next = pi + PSTEP < npages;
+        const char* next = has_next ? page_ptr(pi + PSTEP) : nullptr;
         const int nt = min(kPage, ntok - pi * kPage);  // live tokens in this page (>= 1)
         float sacc[16];
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
             if constexpr (tgt < NPOS) {
                 issue(std::integral_constant<int, tgt>{}, page);
             } else {
-                if (next != nullptr) issue(std::integral_constant<int, tgt - NPOS>{}, next);  // wave-uniform
+                if (has_next) issue(std::integral_constant<int, tgt - NPOS>{}, next);  // wave-uniform
             }
             if constexpr (pos < NB) {
                 // ---- K batch: partial scores of slots pos*TBR .. pos*TBR+TBR-1 ----

@@ -33,8 +33,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // (bf16 x bf16 products are exact in fp32); a native v_mfma_f32_32x32x16_bf16 tile is the next step.
 // MT: 32-row sub-tiles per wave along M.  MT = 2 (128x64 workgroup tile) shares every weight fragment between two
 // MFMAs with independent accumulators: 1.5 instead of 2 LDS fragment reads per MFMA and half the barriers per flop.
-// KQ: 32-deep k slabs staged per tile.  KQ = 4 (128 k per barrier pair) is for the latency-bound shapes -- one
-// workgroup per CU and a short reduction (the logits of config 4: 16 k-steps, each exposing a load round trip).
+// KQ: 32-deep k slabs staged per tile.  Only KQ = 1 is instantiated: 128 k per barrier pair (KQ = 4) was measured
+// SLOWER for the latency-bound fp32 shapes (config 4 logits 23.8 -> 26.0 us, D = 2048 logits 61.8 -> 70.2 us) --
+// unlike the bf16 kernel, whose deep tile is a win (proj_gemm_bf16.hip).
 template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, int KQ = 1>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup
@@ -264,7 +265,7 @@ static int g_latest_compact = 1;  // mli_tune "latest_compact": 0 = the decode p
 void set_latest_compact(int v) { g_latest_compact = v != 0; }
 int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxCompactRows ? 1 : 0; }
 
-static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k": 0 = 32-deep staged tiles everywhere
+static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
 void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
 int deep_k_tiles_enabled() { return g_deep_k_tiles; }
 static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
@@ -282,13 +283,6 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
     if (kTallOk && vec4 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(rows, 128) * z)) {
         dim3 grid(tiles_x, ceil_div_i(rows, 128), z);
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 2>), grid, dim3(kGemmThreads), 0, st, g);
-        return launch_status();
-    }
-    // one workgroup (or fewer) per CU and a reduction of at least 4 deep tiles: stage 128 k per barrier pair
-    constexpr bool kDeepOk = MODE == kPlain || MODE == kPagedLatest || MODE == kNaiveLatest;
-    if (kDeepOk && vec4 && g_deep_k_tiles && g.K >= 512 && (int64_t)tiles_x * ceil_div_i(rows, BM) * z <= 512) {
-        dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 1, 4>), grid, dim3(kGemmThreads), 0, st, g);
         return launch_status();
     }
     dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
