@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
 int chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence); }
 int sv_chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence, kSvUnits); }
 int nt_loads_enabled() { return g_nt_loads; }
-int tuned_chunk_tokens() { return g_chunk_tokens; }
+int tuned_chunk_tokens() { return (getenv("MLI_CHUNK_TOKENS") && atoi(getenv("MLI_CHUNK_TOKENS")) > 0) ? atoi(getenv("MLI_CHUNK_TOKENS")) : g_chunk_tokens; }
 
 int launch_softmax_v_combine(const float* partial, const int* lengths, float* out, int B, int S, int D, int ct,
                              int nchunk, hipStream_t st) {
