@@ -348,6 +348,16 @@ static int g_flash_variant = 0;  // register-budget variants of the scan kernel 
 void set_flash_decode(int v) { g_flash = v != 0; }
 void set_flash_variant(int v) { g_flash_variant = v; }
 
+// Tokens per workgroup of the single-pass scan: the largest power of two <= 512 that still gives two workgroups
+// per CU.  Measured: B=1024, S=4096 -> 512 (256: +2.4 %, 1024: +1 % with ragged lengths); B=256, S=1024 -> 512
+// (scan + combine 49.5 us; 64-token chunks, what the 8192-unit rule of the separate softmax.V kernel picks: 61 us).
+static int fused_chunk_tokens(int B, int S) {
+    if (tuned_chunk_tokens() != 0) return sv_chunk_tokens_for(B, S);  // forced (mli_tune / MLI_CHUNK_TOKENS)
+    int ct = 512;
+    while (ct > 64 && (int64_t)B * ceil_div_i(S, ct) < 512) ct >>= 1;
+    return ct;
+}
+
 // returns 1 when the fused path ran, 0 when the caller should take the three-kernel path, < 0 / > 1 on error
 // phases: bit 0 = scan kernel, bit 1 = combine kernel (3 = the whole block; 1 / 2 let bench.py time them apart)
 template <class E>
@@ -364,7 +374,7 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     const bool solo = g_flash_variant == 3 && S > 128 && !dsplit;
     // short sequences with a full batch: one workgroup per row (no partials, no combine launch) beats two 64-token
     // chunks (README workload, S = 128: 200 vs 209 us)
-    const int ct = solo ? 128 : (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : sv_chunk_tokens_for(B, S);
+    const int ct = solo ? 128 : (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : fused_chunk_tokens(B, S);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     const size_t stats_bytes = stats_region_bytes_for(B, S);
