@@ -56,7 +56,10 @@ class Workload:
         g.manual_seed(seed)
         rng = np.random.default_rng(seed)
         self.dev = dev
-        lengths = rng.integers(S // 4, 3 * S // 4 + 1, size=B).astype(np.int32)
+        hi = min(3 * S // 4, S - headroom - 3)  # every row must stay below max_seq for the whole run
+        if hi < S // 4:
+            raise SystemExit(f"workload {name}: {headroom - 8} steps do not fit into max_seq {S}; use fewer --steps")
+        lengths = rng.integers(S // 4, hi + 1, size=B).astype(np.int32)
         if os.environ.get("MLI_BENCH_LENGTHS") == "uniform":  # diagnostic: no length variation between rows
             lengths[:] = S // 2
         assert int(lengths.max()) + headroom + 2 < S
@@ -493,7 +496,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
-                        f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[S/4,3S/4], "
+                        f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[{wl.S // 4},{int(wl.lengths_host.max())}], "
                         f"{'bf16 pages and weights, fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}",
             "rows_per_gpu": wl.B, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
             "mean_length": float(wl.lengths_host.mean()),
