@@ -205,6 +205,8 @@ struct mli_engine {
                                                      cfg.n_forward_rounds);
         const double t3 = now();
         insert(free_slots);
+        if (paged() && processing_storage.size() == 0 && item_storage.new_count() > 0)
+            throw std::runtime_error("paged engine: the page pool is too small for the next queued item");
         const double t4 = now();
         t_forward += t1 - t0; t_result += t2 - t1; t_pages += t3 - t2; t_insert += t4 - t3;
         ++iterations;

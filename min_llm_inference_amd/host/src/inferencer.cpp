@@ -1,6 +1,7 @@
 #include "inferencer.h"
 
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 #include "bf16_extension.h"
@@ -27,6 +28,13 @@ struct Range {  // roctx range, closed on scope exit
     explicit Range(const char* name) { mli::runtime::range_push(name); }
     ~Range() { mli::runtime::range_pop(); }
 };
+
+// Nothing in flight, items still queued, and the admission just refused the head item although every page is free:
+// the pool cannot hold it.  The reference's loop spins forever here; a host waiting on a GPU box should get an error.
+void throw_if_stuck(ItemStorage& item_storage, ProcessingStorage& processing_storage) {
+    if (processing_storage.size() == 0 && item_storage.new_count() > 0)
+        throw std::runtime_error("paged engine: the page pool is too small for the next queued item");
+}
 
 // Shared body of the two paged engines; `forward` hides the model type (and its GemmHandle).
 template <typename Forward>
@@ -67,6 +75,7 @@ void run_paged_engine(ItemStorage& item_storage, ProcessingStorage& processing_s
                                                 processing_storage, memory_block_manager, paged_attention_manager,
                                                 n_forward_rounds);
         }
+        throw_if_stuck(item_storage, processing_storage);
     }
     get_global_throughput_counter().print_throughput();
 }

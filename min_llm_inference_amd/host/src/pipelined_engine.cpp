@@ -54,8 +54,14 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
     auto admit = [&](long long step) {
         Range r("insert_new_items");
         TensorInt& staging = new_idx_host[step & 1];
+        const bool nothing_in_flight = processing_storage.size() == 0;  // then every slot and every page is free
         PagedAdmission adm = admit_new_items(inp_host.data(), lengths_host.data(), staging.data(), B, S, item_storage,
                                              processing_storage, pool, pages, /*n_forward_rounds=*/1);
+        if (nothing_in_flight && adm.slots.empty() && item_storage.new_count() > 0) {
+            // the whole pool cannot hold the head item: an error, not the endless loop of the reference's engine
+            mli::runtime::synchronize();
+            throw std::runtime_error("paged engine: the page pool is too small for the next queued item");
+        }
         if (adm.slots.empty()) {
             pages.maybe_flush_changes();
             return 0;
@@ -149,6 +155,7 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
             allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/1);
         ++step;
         if (is_done(item_storage, processing_storage)) break;
+
     }
     mli::runtime::synchronize();  // forward(step) is still in flight (every row empty): drain before the tensors go
     return step + 1;

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <map>
 #include <random>
+#include <stdexcept>
 #include <vector>
 
 #include "constants.h"
@@ -170,6 +171,22 @@ int main() {
         const int max_prompt = 1 + rng() % (S - 2);
         const int eof_bias = (seed % 3 == 0) ? 0 : static_cast<int>(rng() % 12);
         run_case(1000 + seed, B, S, n_blocks, n_items, max_prompt, eof_bias);
+    }
+    {   // a pool that cannot hold even one row: an error, not an endless loop
+        World w(4, 64, DEFAULT_INIT_NUM_BLOCKS - 1);
+        w.items.add_new_item(IdTokensPair(0, std::vector<int>{1, 2, 3}));
+        FakeModel model{4, 64, 0, std::vector<uint64_t>(4, 0), &w.pages};
+        bool threw = false;
+        try {
+            run_paged_engine_pipelined(w.items, w.processing, w.pool, w.pages, 4, 64,
+                                       [&](const TensorInt& inp, TensorInt& len, const TensorInt& idx, TensorInt& res, int n_new) {
+                                           model.forward(inp, len, idx, res, n_new);
+                                       });
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+        std::printf("%s pool too small for any row: reported\n", threw ? "[ OK ]" : "[FAIL]");
     }
     std::printf("%d failure(s)\n", g_failures);
     return g_failures != 0;

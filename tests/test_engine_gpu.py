@@ -211,3 +211,19 @@ def test_pipelined_engine_random_configurations(mli, dev, seed):
     assert st_seq.total_tokens == st_pip.total_tokens
     for item_id, _ in items:
         assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), (item_id, B, S, D, n_blocks)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_pool_too_small_for_any_row_is_an_error_not_a_hang(mli, dev, pipelined):
+    """Fewer pages than a row's initial allotment: the reference's loop would spin forever; here run() fails."""
+    from min_llm_inference_amd import MliError, engine as eng
+    B, S, D, V = 4, 64, 64, 1024
+    model = make_model(57, V, S, D)
+    e = eng.Engine(eng.PAGED, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
+                   n_blocks=3)
+    if pipelined:
+        e.set_pipelined()
+    e.add_item(0, np.arange(5, dtype=np.int32))
+    with pytest.raises(MliError, match="page pool is too small"):
+        e.run()
+    e.close()
