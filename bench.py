@@ -265,7 +265,14 @@ def cpu_baseline(wl, budget_s=12.0):
             list(pool.map(lambda i: rows(cuts[i], cuts[i + 1]), range(nthr)))
             mt_t += time.perf_counter() - t0
             mt_reps += 1
-    return {"value": live * reps / total_t, "unit": "tokens/s", "cores": 1, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": live * reps / total_t, "unit": "tokens/s", "cores": 1, "kind": "port", "host_cpu": cpu_model,
+            "host_cores_visible": cores,
             "sample": f"{reps} decode steps over {n} of {wl.B} rows of the same workload shape (contiguous layout, "
                       f"n_new=0, fp32 -- the reference's CPU path has no paged or bf16 form), {total_t:.1f} s "
                       f"single-threaded oracle_cpu.c",
