@@ -38,9 +38,13 @@ static int g_qkt_token_batch = 8;
 // worth a few percent (measured on MI355X at B=1024, S=4096: q.K^T 256, softmax.V 512).
 // MLI_CHUNK_TOKENS (power of two in [64, 1024]) overrides the heuristic for tuning runs.
 constexpr int kQktUnits = 16384;  // q.K^T is insensitive to the chunk size (341-349 us for 64..512 tokens at config 4)
-constexpr int kSvUnits = 8192;    // softmax.V prefers larger chunks: fewer partial sums to write and combine
+// softmax.V: at most 512 tokens (fewer partial sums to write and combine than q.K^T's chunks), shrunk until there are
+// >= 2048 units.  Measured: B=1024, S=4096 -> 512 (8192 units); B=256, S=1024 -> 128 (26.5 us; 64: 32.8, 256: 27.8,
+// 512: 44.1).
+constexpr int kSvUnits = 2048;
+constexpr int kSvMaxChunkTokens = 512;
 
-static int pick_chunk_tokens(int n_batch, int n_sequence, int min_units = kQktUnits) {
+static int pick_chunk_tokens(int n_batch, int n_sequence, int min_units = kQktUnits, int max_ct = kMaxChunkTokens) {
     static const int forced = [] {
         const char* e = getenv("MLI_CHUNK_TOKENS");
         const int v = e ? atoi(e) : 0;
@@ -48,7 +52,7 @@ static int pick_chunk_tokens(int n_batch, int n_sequence, int min_units = kQktUn
     }();
     if (forced) return forced;
     if (g_chunk_tokens) return g_chunk_tokens;
-    int ct = kMaxChunkTokens;
+    int ct = max_ct;
     while (ct > kMinChunkTokens && (int64_t)n_batch * ceil_div_i(n_sequence, ct) < min_units) ct >>= 1;
     return ct;
 }
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
 int chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence); }
-int sv_chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence, kSvUnits); }
+int sv_chunk_tokens_for(int n_batch, int n_sequence) { return pick_chunk_tokens(n_batch, n_sequence, kSvUnits, kSvMaxChunkTokens); }
 int nt_loads_enabled() { return g_nt_loads; }
 int tuned_chunk_tokens() { return (getenv("MLI_CHUNK_TOKENS") && atoi(getenv("MLI_CHUNK_TOKENS")) > 0) ? atoi(getenv("MLI_CHUNK_TOKENS")) : g_chunk_tokens; }
 
@@ -474,7 +478,7 @@ static int launch_softmax_v_impl(float* probs, const void* src, const int* lengt
     const int Dv = D / VEC;
     const int nj = min(2, ceil_div_i(Dv, kWave));  // <= 64 VGPRs -> 8 waves/SIMD; wider rows are swept in slices
     const int slice_v = kWave * nj;
-    int ct = pick_chunk_tokens(B, S, kSvUnits);
+    int ct = pick_chunk_tokens(B, S, kSvUnits, kSvMaxChunkTokens);
     const int nchunk = ceil_div_i(S, ct);
     const int direct = nchunk == 1;
     float* dst = out;
