@@ -297,6 +297,25 @@ def gemm_report(wl, lengths, times):
                       "118 TFLOP/s fp32 / 551 TFLOP/s bf16 (DESIGN.md 3.5)" if wl.D <= 512 else ""))}
 
 
+def large_gemm_report(dev):
+    """The same projection kernels where they are not latency-bound: x[1024, 2048].[Wk|Wq|Wv] (the reference's
+    profiling shape, bench.py --workload e1), both element types, measured here so that the MFMA figure in the JSON
+    is not only the 1.6-GFLOP launch of config 4."""
+    out = {"shape": "B=1024, D=2048 (25.8 GFLOP per launch)", "unit": "TFLOP/s"}
+    for dt in ("f32", "bf16"):
+        try:
+            w = Workload("e1", dev, 0xE1, headroom=8, dtype=dt)
+            fn = [v for k, v in w.kernels().items() if k.startswith("get_latest")][0]
+            ms = time_kernel(fn, 100)
+            tf = 2.0 * w.B * w.D * 3 * w.D / (ms * 1e-3) / 1e12
+            out[dt] = {"avg_launch_ms": ms, "achieved": tf, "peak": MFMA_PEAK_TFLOPS[dt], "frac": tf / MFMA_PEAK_TFLOPS[dt]}
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:  # never let the side measurement take the bench line down
+            out[dt] = {"error": str(e)[:200]}
+    return out
+
+
 def pmc_traffic(workload, which, layout, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this command
     (profiles/pmc_<workload>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE).  bench.py cannot
@@ -533,6 +552,7 @@ def main():
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms,
             "kernel_ms": times,
             "projection_gemm": gemm_report(wl, lengths_now, times),
+            "projection_gemm_d2048": large_gemm_report(dev),
             "step_algorithmic_bytes": alg["step"],
             "step_gbs": alg["step"] / (out["ms_per_step"] * 1e-3) / 1e9,
             "measured_copy_gbs": measure_copy_gbs(dev),
