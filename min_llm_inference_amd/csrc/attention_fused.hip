@@ -17,6 +17,16 @@
 
 namespace mli {
 
+// -DMLI_SCAN_TRACE: every workgroup of the scan records where it ran and when it passed five points (100 MHz
+// wall clock), read back by mli_debug_scan_trace -- a diagnostic build for tools/scan_trace.py, never the product.
+#ifdef MLI_SCAN_TRACE
+constexpr int kTraceSlots = 16384;
+__device__ unsigned long long mli_scan_trace[kTraceSlots * 8];
+#define MLI_TRACE(i) do { if (threadIdx.x == 0 && trace_id < kTraceSlots) mli_scan_trace[trace_id * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MLI_TRACE(i) do { } while (0)
+#endif
+
 constexpr int kFuThreads = 256;
 constexpr int kFuWaves = kFuThreads / kWave;
 
@@ -72,15 +82,38 @@ template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = fals
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
-    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct) {
+    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, unsigned* __restrict__ ticket) {
     constexpr int EPL = E::EPL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
     float* red = reinterpret_cast<float*>(smem_raw + (size_t)(ct / kPage) * 8);            // [waves][NJ*64*EPL]
     __shared__ float2 wave_ml[WAVES];
 
-    const int b = blockIdx.x;
-    const int c = blockIdx.y;
+    // Which (row, chunk) this workgroup takes.  Static: its grid position.  With a ticket counter: the next item in
+    // the same order (rows fast, then chunks), whichever workgroup asks first.  Workgroups are dealt to the 8 XCDs
+    // round-robin by grid position, so the static form gives every XCD a fixed eighth of the rows -- with ragged
+    // lengths the XCDs' totals differ by +-10 % and the slowest one sets the kernel time (tools/scan_trace.py: last
+    // workgroup of an XCD at 615..701 us); tickets let the XCDs that run ahead take more items.
+    int b = blockIdx.x;
+    int c = blockIdx.y;
+    if (ticket != nullptr) {
+        __shared__ unsigned item_sh;
+        if (threadIdx.x == 0) item_sh = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned item = item_sh;
+        if (item >= gridDim.x * gridDim.y) return;  // cannot happen with a zeroed counter; never index out of range
+        b = (int)(item % gridDim.x);
+        c = (int)(item / gridDim.x);
+    }
+#ifdef MLI_SCAN_TRACE
+    const int trace_id = b + gridDim.x * c;
+    if (threadIdx.x == 0 && trace_id < kTraceSlots) {
+        mli_scan_trace[trace_id * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        mli_scan_trace[trace_id * 8 + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+        mli_scan_trace[trace_id * 8 + 1] = 0;
+    }
+#endif
+    MLI_TRACE(0);
     const int L = min(lengths[b], S);
     const int s0 = c * ct;
     const int lane = threadIdx.x & (kWave - 1);
@@ -100,6 +133,7 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     for (int i = threadIdx.x; i < npages; i += (WAVES * kWave))
         ptr_sh[i] = page_table[(int64_t)b * (S / kPage) + s0 / kPage + i];
     __syncthreads();
+    MLI_TRACE(1);
 
     const int Du = D / EPL;  // lane-units per row
     const float scale = sqrtf((float)D);
@@ -246,7 +280,11 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
             }
         });
         page = next;
+#ifdef MLI_SCAN_TRACE
+        if (pi == p_first) MLI_TRACE(2);
+#endif
     }
+    MLI_TRACE(3);
 
     if constexpr (DS) {
         // every wave holds the chunk's (max, sum) and its own slice of the output
@@ -305,6 +343,10 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     } else if (threadIdx.x == 0) {
         ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
     }
+    MLI_TRACE(4);
+#ifdef MLI_SCAN_TRACE
+    if (threadIdx.x == 0 && trace_id < kTraceSlots) mli_scan_trace[trace_id * 8 + 7] = (unsigned long long)npages;
+#endif
 }
 
 // grid = (B, kCombineParts).  Every part merges the row's chunk statistics (cheap, identical result), part 0 also
@@ -345,6 +387,8 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
 
 static int g_flash = 1;
 static int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
+static int g_dynamic_items = 1;  // mli_tune "scan_dynamic_items": ticketed (row, chunk) assignment
+void set_dynamic_items(int v) { g_dynamic_items = v != 0; }
 void set_flash_decode(int v) { g_flash = v != 0; }
 void set_flash_variant(int v) { g_flash_variant = v; }
 
@@ -386,6 +430,16 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + stats_bytes);
     }
     const int ml_per_row = ceil_div_i(S, 64);
+    // ticket counter for the dynamic (row, chunk) assignment: in the part of the workspace the partial sums of this
+    // chunk size leave unused, zeroed on the stream before every launch
+    unsigned* ticket = nullptr;
+    if (!direct && g_dynamic_items && (phases & 1) && (int64_t)B * nchunk >= 1024) {
+        const size_t off = (stats_bytes + (size_t)B * nchunk * D * sizeof(float) + 255) & ~(size_t)255;
+        if (off + sizeof(unsigned) <= ws_bytes) {
+            ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + off);
+            if (hipMemsetAsync(ticket, 0, sizeof(unsigned), st) != hipSuccess) ticket = nullptr;
+        }
+    }
     const int waves = solo ? 1 : kFuWaves;
     const size_t smem = (size_t)(ct / kPage) * 8 +
                         (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
@@ -394,7 +448,7 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
 #define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES, ...)                                                              \
     hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
                        dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \
-                       ml_per_row, nchunk, direct)
+                       ml_per_row, nchunk, direct, ticket)
     if (phases & 1) {
         if (dsplit) {
             if (nj_ds == 1) {
@@ -462,3 +516,16 @@ extern "C" int mli_decode_scan_paged(const float* q_output, const void* const* p
 namespace mli {
 
 }  // namespace mli
+
+#ifdef MLI_SCAN_TRACE
+extern "C" int mli_debug_scan_trace(unsigned long long* host, int n_slots) {
+    if (n_slots > mli::kTraceSlots) n_slots = mli::kTraceSlots;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mli::mli_scan_trace), (size_t)n_slots * 8 * sizeof(unsigned long long));
+}
+extern "C" int mli_debug_scan_trace_clear(void) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(mli::mli_scan_trace));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * mli::kTraceSlots * 8);
+}
+#endif

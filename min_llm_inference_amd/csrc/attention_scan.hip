@@ -23,6 +23,7 @@ constexpr int kMinChunkTokens = 64;
 void set_bf16_native_mfma(int v);  // proj_gemm.hip
 void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
+void set_dynamic_items(int v);
 void set_gemm_tall_tiles(int v);
 void set_deep_k_tiles(int v);
 void set_fill_compact(int v);
@@ -669,6 +670,8 @@ int mli_tune(const char* key, int value) {
         mli::set_deep_k_tiles(value);
     } else if (k == "gemm_tall_tiles") {
         mli::set_gemm_tall_tiles(value);
+    } else if (k == "scan_dynamic_items") {
+        mli::set_dynamic_items(value);
     } else if (k == "flash_variant") {
         mli::set_flash_variant(value);
     } else if (k == "flash_decode") {

@@ -68,6 +68,36 @@ __global__ __launch_bounds__(256) void read_regions(const float4* __restrict__ s
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// the decode scan's order inside a page: K rows 0-7, K rows 8-15, V rows 0-7, V rows 8-15 (1 KiB pieces, bf16 D=512),
+// UNROLL = 8 rows per batch, one batch consumed while the next is in flight is NOT modelled (plain issue / wait)
+template <bool NT>
+__global__ __launch_bounds__(256) void read_blocks_kv_order(const float4* __restrict__ src, float* __restrict__ sink,
+                                                             const int* __restrict__ perm, int nblocks, long stride_f4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.f;
+    for (long bi = wave; bi < nblocks; bi += nwaves) {
+        const long base = (long)perm[bi] * 16 * stride_f4;
+#pragma unroll
+        for (int phase = 0; phase < 4; ++phase) {
+            const int seg = phase < 2 ? 1 : 2;           // K, K, V, V
+            const int r0 = (phase & 1) * 8;
+            f4v v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f4v __attribute__((address_space(1)))* p =
+                    (const f4v __attribute__((address_space(1)))*)(src + base + (long)(r0 + u) * stride_f4 + seg * 64 + lane);
+                v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // page-shaped access: 16 rows per block, blocks visited through a permutation (scattered pages); UNROLL rows of
 // one block in flight per wave; reads `row_f4` float4 at `col_f4` of every row (K only, or K|V)
 template <int UNROLL, bool NT, int EXTRA = 0>
@@ -141,17 +171,23 @@ float time_ms(F f, int reps) {
     return ms / reps;
 }
 
+// MEMBENCH_LDS=<bytes of dynamic LDS per workgroup>: limits the workgroups per CU (70000 -> 2 per CU = the occupancy of
+// the decode scan kernel) without touching the kernels
+static unsigned g_lds = 0;
+
 int main() {
+    if (const char* e = getenv("MEMBENCH_LDS")) g_lds = (unsigned)atoi(e);
+    std::printf("dynamic LDS per workgroup: %u bytes\n", g_lds);
     const long n4 = 1L << 28;  // 4 GiB source
     float4 *src, *dst; float* sink;
     CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(src, 1, n4 * 16));
     for (int grid : {1024, 2048, 4096, 8192, 16384}) {
-        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(grid), dim3(256), 0, 0, src, dst, n4); }, 5);
+        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(grid), dim3(256), g_lds, 0, src, dst, n4); }, 5);
         printf("copy unroll4 grid %5d: %.1f GB/s (r+w)\n", grid, 2.0 * n4 * 16 / ms / 1e6);
     }
     {
-        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<8>, dim3(4096), dim3(256), 0, 0, src, dst, n4); }, 5);
+        float ms = time_ms([&] { hipLaunchKernelGGL(copy_f4<8>, dim3(4096), dim3(256), g_lds, 0, src, dst, n4); }, 5);
         printf("copy unroll8 grid  4096: %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
         ms = time_ms([&] { CK(hipMemcpyAsync(dst, src, n4 * 16, hipMemcpyDeviceToDevice, 0)); }, 5);
         printf("hipMemcpy D2D         : %.1f GB/s (r+w)\n", 2.0 * n4 * 16 / ms / 1e6);
@@ -160,9 +196,9 @@ int main() {
         const long f4w = kib * 64;                      // float4 per wave region
         if (f4w % (64 * 16) != 0 || f4w > n4) continue;  // a region must hold whole UNROLL=16 batches (bounds!)
         for (int grid : {2048, 8192}) {
-            float a = time_ms([&] { hipLaunchKernelGGL((read_regions<4, false>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
-            float b = time_ms([&] { hipLaunchKernelGGL((read_regions<4, true>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
-            float c = time_ms([&] { hipLaunchKernelGGL((read_regions<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, n4, f4w); }, 5);
+            float a = time_ms([&] { hipLaunchKernelGGL((read_regions<4, false>), dim3(grid), dim3(256), g_lds, 0, src, sink, n4, f4w); }, 5);
+            float b = time_ms([&] { hipLaunchKernelGGL((read_regions<4, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, n4, f4w); }, 5);
+            float c = time_ms([&] { hipLaunchKernelGGL((read_regions<16, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, n4, f4w); }, 5);
             printf("read regions %4ld KiB/wave grid %5d: u4 %.0f  u4-nt %.0f  u16-nt %.0f GB/s\n", kib, grid,
                    n4 * 16.0 / a / 1e6, n4 * 16.0 / b / 1e6, n4 * 16.0 / c / 1e6);
         }
@@ -175,11 +211,11 @@ int main() {
     for (auto& sh : shapes) {
         long rows = (n4 - sh.row_f4) / sh.stride_f4;
         for (int grid : {2048, 4096, 8192}) {
-            float ms4 = time_ms([&] { hipLaunchKernelGGL(read_rows<4>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
-            float ms8 = time_ms([&] { hipLaunchKernelGGL(read_rows<8>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
-            float ms16 = time_ms([&] { hipLaunchKernelGGL(read_rows<16>, dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
-            float nt8 = time_ms([&] { hipLaunchKernelGGL((read_rows<8, true>), dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
-            float nt16 = time_ms([&] { hipLaunchKernelGGL((read_rows<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float ms4 = time_ms([&] { hipLaunchKernelGGL(read_rows<4>, dim3(grid), dim3(256), g_lds, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float ms8 = time_ms([&] { hipLaunchKernelGGL(read_rows<8>, dim3(grid), dim3(256), g_lds, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float ms16 = time_ms([&] { hipLaunchKernelGGL(read_rows<16>, dim3(grid), dim3(256), g_lds, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float nt8 = time_ms([&] { hipLaunchKernelGGL((read_rows<8, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
+            float nt16 = time_ms([&] { hipLaunchKernelGGL((read_rows<16, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, rows, sh.row_f4, sh.stride_f4); }, 5);
             double bytes = (double)rows * sh.row_f4 * 16;
             printf("read %-44s grid %5d: u4 %.0f  u8 %.0f  u16 %.0f | nt u8 %.0f  nt u16 %.0f GB/s\n", sh.name, grid, bytes / ms4 / 1e6, bytes / ms8 / 1e6, bytes / ms16 / 1e6, bytes / nt8 / 1e6, bytes / nt16 / 1e6);
         }
@@ -205,12 +241,16 @@ int main() {
             for (int mode = 0; mode < 2; ++mode) {
                 CK(hipMemcpy(dperm, mode ? shuf.data() : lin.data(), sizeof(int) * nblocks, hipMemcpyHostToDevice));
                 for (int grid : {2048, 8192}) {
-                    float a = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
-                    float b = time_ms([&] { hipLaunchKernelGGL((read_blocks<16, true>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
-                    float c8 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 8>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
-                    float c16 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 16>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
-                    float c32 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 32>), dim3(grid), dim3(256), 0, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float a = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float b = time_ms([&] { hipLaunchKernelGGL((read_blocks<16, true>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c8 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 8>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c16 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 16>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
+                    float c32 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 32>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
                     printf("blocks %-62s %s grid %5d: nt u8 %.0f  nt u16 %.0f | u8 + 8/16/32 VALU per load: %.0f %.0f %.0f GB/s\n", sh.name, mode ? "shuffled" : "linear  ", grid, bytes / a / 1e6, bytes / b / 1e6, bytes / c8 / 1e6, bytes / c16 / 1e6, bytes / c32 / 1e6);
+                    if (sh.row_f4 == 128 && sh.stride_f4 == 192) {
+                        float k = time_ms([&] { hipLaunchKernelGGL((read_blocks_kv_order<true>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.stride_f4); }, 5);
+                        printf("       same blocks in the scan's order (K 0-7, K 8-15, V 0-7, V 8-15): %.0f GB/s\n", bytes / k / 1e6);
+                    }
                 }
             }
             CK(hipFree(dperm));

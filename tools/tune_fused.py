@@ -17,9 +17,9 @@ alg = wl.algorithmic_bytes(wl.lengths_host)
 print(f"workload {name} {dtype}: step attention bytes {alg['step']/1e9:.3f} GB")
 scan = [v for k, v in wl.kernels().items() if k.startswith("fused_decode_scan")][0]
 for rnd in range(3):
-    for variant in (0,):
-        for ct in (256, 512, 1024):
-            lib.mli_tune(b"flash_variant", variant)
+    for dyn in (1, 0):
+        for ct in (0, 1024):
+            lib.mli_tune(b"scan_dynamic_items", dyn)
             lib.mli_tune(b"chunk_tokens", ct)
             t = bench.time_kernel(scan, 20)
-            print(f"round {rnd} variant {variant} ct {ct:5d}: scan {t*1e3:8.1f} us  {alg['scan']/t/1e6:7.0f} GB/s", flush=True)
+            print(f"round {rnd} dynamic items {dyn} ct {ct:5d}: scan {t*1e3:8.1f} us  {alg['scan']/t/1e6:7.0f} GB/s", flush=True)
