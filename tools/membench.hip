@@ -98,6 +98,54 @@ __global__ __launch_bounds__(256) void read_blocks_kv_order(const float4* __rest
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// the decode scan's WORKGROUP structure around the same loads: an item = 32 blocks for the 4 waves of a workgroup
+// (8 each, K 0-7, K 8-15, V 0-7, V 8-15 per block), with what the scan does around an item: block indices staged in
+// LDS behind a barrier (the page pointers), and at the end the waves meet at a barrier, combine 2 KiB through LDS and
+// store it (the chunk's partial result).  ITEM_SYNC = false drops the barriers and the LDS / store epilogue.
+template <bool NT, bool ITEM_SYNC>
+__global__ __launch_bounds__(256) void read_blocks_items(const float4* __restrict__ src, float* __restrict__ sink,
+                                                          const int* __restrict__ perm, int nblocks, long stride_f4,
+                                                          float* __restrict__ partial) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __shared__ int idx_sh[32];
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    const int nitems = nblocks / 32;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (ITEM_SYNC) {
+            if (threadIdx.x < 32) idx_sh[threadIdx.x] = perm[item * 32 + threadIdx.x];
+            __syncthreads();
+        }
+        for (int k = wave; k < 32; k += 4) {
+            const int blk = ITEM_SYNC ? __builtin_amdgcn_readfirstlane(idx_sh[k]) : perm[item * 32 + k];
+            const long base = (long)blk * 16 * stride_f4;
+#pragma unroll
+            for (int phase = 0; phase < 4; ++phase) {
+                const int seg = phase < 2 ? 1 : 2;
+                const int r0 = (phase & 1) * 8;
+                f4v v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const f4v __attribute__((address_space(1)))* p =
+                        (const f4v __attribute__((address_space(1)))*)(src + base + (long)(r0 + u) * stride_f4 + seg * 64 + lane);
+                    v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+            }
+        }
+        if (ITEM_SYNC) {
+            for (int i = lane; i < 512; i += 64) red[wave][i] = acc + i;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 512; i += 256)
+                partial[(long)item * 512 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+            __syncthreads();
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // page-shaped access: 16 rows per block, blocks visited through a permutation (scattered pages); UNROLL rows of
 // one block in flight per wave; reads `row_f4` float4 at `col_f4` of every row (K only, or K|V)
 template <int UNROLL, bool NT, int EXTRA = 0>
@@ -247,6 +295,16 @@ int main() {
                     float c16 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 16>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
                     float c32 = time_ms([&] { hipLaunchKernelGGL((read_blocks<8, true, 32>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.row_f4, sh.col_f4, sh.stride_f4); }, 5);
                     printf("blocks %-62s %s grid %5d: nt u8 %.0f  nt u16 %.0f | u8 + 8/16/32 VALU per load: %.0f %.0f %.0f GB/s\n", sh.name, mode ? "shuffled" : "linear  ", grid, bytes / a / 1e6, bytes / b / 1e6, bytes / c8 / 1e6, bytes / c16 / 1e6, bytes / c32 / 1e6);
+                    if (sh.row_f4 == 128 && sh.stride_f4 == 192 && grid == 8192) {
+                        float* part;
+                        CK(hipMalloc(&part, sizeof(float) * 512 * (size_t)(nblocks / 32 + 1)));
+                        for (int g2 : {512, 2048}) {
+                            float y = time_ms([&] { hipLaunchKernelGGL((read_blocks_items<true, true>), dim3(g2), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.stride_f4, part); }, 5);
+                            float n = time_ms([&] { hipLaunchKernelGGL((read_blocks_items<true, false>), dim3(g2), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.stride_f4, part); }, 5);
+                            printf("       workgroup items of 32 blocks, grid %4d: with barriers + LDS merge + partial store %.0f GB/s, without %.0f GB/s\n", g2, (double)(nblocks / 32) * 32 * 16 * sh.row_f4 * 16 / y / 1e6, (double)(nblocks / 32) * 32 * 16 * sh.row_f4 * 16 / n / 1e6);
+                        }
+                        CK(hipFree(part));
+                    }
                     if (sh.row_f4 == 128 && sh.stride_f4 == 192) {
                         float k = time_ms([&] { hipLaunchKernelGGL((read_blocks_kv_order<true>), dim3(grid), dim3(256), g_lds, 0, src, sink, dperm, nblocks, sh.stride_f4); }, 5);
                         printf("       same blocks in the scan's order (K 0-7, K 8-15, V 0-7, V 8-15): %.0f GB/s\n", bytes / k / 1e6);
