@@ -229,8 +229,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
  *                      once for K and V, online softmax) when emb_dim fits (fp32 <= 2048, bf16 <= 4096);
  *                      0 = separate q.K^T / softmax / softmax.V passes
- *   "scan_dynamic_items" 1 (default) = the single-pass scan hands its (row, chunk) items out through a ticket counter
- *                      (balances the XCDs on ragged lengths), 0 = by grid position
+ *   "scan_dynamic_items" 1 = the single-pass scan hands its (row, chunk) items out through a ticket counter (balances
+ *                      the XCDs on ragged lengths; the counter reset costs what it gains), 0 (default) = by grid position
  *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three
  *                      launches as the reference (qkt, softmax_in_place_with_lengths, softmax_v), -1 (default) =
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
