@@ -110,6 +110,13 @@ def test_config4_repeat_is_bit_identical_and_forms_agree(mli, c4):
     p0, o0 = scan()
     p1, o1 = scan()
     assert torch.equal(p0, p1) and torch.equal(o0, o1), "same launch twice: bit-identical"
+    try:                                                           # ticketed (row, chunk) assignment: same items, other owners
+        assert mli.mli_tune(b"scan_dynamic_items", 1) == 0
+        p2, o2 = scan()
+        p3, o3 = scan()                                            # the counter is re-zeroed for every launch
+    finally:
+        mli.mli_tune(b"scan_dynamic_items", 0)
+    assert torch.equal(p0, p2) and torch.equal(o0, o2) and torch.equal(p0, p3) and torch.equal(o0, o3)
     try:
         for ct in (256, 1024):                                     # other split points, other merge trees
             assert mli.mli_tune(b"chunk_tokens", ct) == 0
