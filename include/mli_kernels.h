@@ -229,6 +229,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
  *                      once for K and V, online softmax) when emb_dim fits (fp32 <= 2048, bf16 <= 4096);
  *                      0 = separate q.K^T / softmax / softmax.V passes
+ *   "scan_partial_last" 1 (default) = the single-pass scan runs full chunks first and every row's partial chunk in a
+ *                      last grid row (shorter tail), 0 = plain chunk order
  *   "scan_dynamic_items" 1 = the single-pass scan hands its (row, chunk) items out through a ticket counter (balances
  *                      the XCDs on ragged lengths; the counter reset costs what it gains), 0 (default) = by grid position
  *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three

@@ -82,7 +82,7 @@ template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = fals
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
-    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, unsigned* __restrict__ ticket) {
+    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, unsigned* __restrict__ ticket, int partial_last) {
     constexpr int EPL = E::EPL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
@@ -115,6 +115,17 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
 #endif
     MLI_TRACE(0);
     const int L = min(lengths[b], S);
+    if (partial_last) {
+        // Largest items first: grid rows 0 .. nchunk-1 run only the FULL chunks, one extra grid row at the end runs each
+        // row's partial chunk.  In plain chunk order the last workgroups to start are often full ones, and the launch
+        // ends with a long tail at a fraction of the bandwidth (tools/scan_trace.py).
+        if (c == nchunk_max) {
+            if (L % ct == 0) return;            // no partial chunk (covers the empty row)
+            c = L / ct;
+        } else if ((c + 1) * ct > L) {
+            return;                             // empty, or the partial chunk (the extra grid row takes it)
+        }
+    }
     const int s0 = c * ct;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -387,6 +398,8 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
 
 static int g_flash = 1;
 static int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
+static int g_partial_last = 1;   // mli_tune "scan_partial_last": full chunks first, each row's partial chunk in a last grid row
+void set_partial_last(int v) { g_partial_last = v != 0; }
 // mli_tune "scan_dynamic_items": ticketed (row, chunk) assignment.  Off by default: it shortens the kernel by 0.6-1.5 %
 // (4-10 us at config 4), and the hipMemsetAsync that zeroes the counter before every launch costs the stream ~8 us.
 static int g_dynamic_items = 0;
@@ -446,11 +459,13 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     const size_t smem = (size_t)(ct / kPage) * 8 +
                         (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
     dim3 grid(B, nchunk);
+    const int partial_last = (!direct && ticket == nullptr && g_partial_last) ? 1 : 0;
+    if (partial_last) grid = dim3(B, nchunk + 1);
     const bool nt = nt_loads_enabled();
 #define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES, ...)                                                              \
     hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
                        dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \
-                       ml_per_row, nchunk, direct, ticket)
+                       ml_per_row, nchunk, direct, ticket, partial_last)
     if (phases & 1) {
         if (dsplit) {
             if (nj_ds == 1) {

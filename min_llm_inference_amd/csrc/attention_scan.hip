@@ -24,6 +24,7 @@ void set_bf16_native_mfma(int v);  // proj_gemm.hip
 void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
 void set_dynamic_items(int v);
+void set_partial_last(int v);
 void set_gemm_tall_tiles(int v);
 void set_deep_k_tiles(int v);
 void set_fill_compact(int v);
@@ -670,6 +671,8 @@ int mli_tune(const char* key, int value) {
         mli::set_deep_k_tiles(value);
     } else if (k == "gemm_tall_tiles") {
         mli::set_gemm_tall_tiles(value);
+    } else if (k == "scan_partial_last") {
+        mli::set_partial_last(value);
     } else if (k == "scan_dynamic_items") {
         mli::set_dynamic_items(value);
     } else if (k == "flash_variant") {
