@@ -2,8 +2,9 @@
 """Decode-step benchmark for the MI355X decode attention path.
 
     python bench.py --gpus 1 --steps 50 --warmup 10            # one GPU
+    python bench.py --gpus N --steps K --warmup W               # N GPUs: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W    # N GPUs, one rank per GPU (RCCL)
+        --master-port P bench.py --gpus N --steps K --warmup W    # the same, launched by the caller (RCCL)
 
 One step = one decode step of the continuous batch on synthetic state already resident in HBM:
 attention block (projection GEMM with page gather/scatter -> q.K^T -> masked softmax -> softmax.V)
@@ -388,6 +389,31 @@ def run_engine_mode(args, rank, world, dev):
     return Total, (B, S, D, V, n_blocks)
 
 
+def launcher_command(n_ranks, argv, port):
+    """The command `python bench.py --gpus N` runs on behalf of the caller: the same launch line the driver uses
+    (one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_ranks, argv):
+    """Start N fresh rank processes (children of this one, never an exec: this process stays a plain launcher that
+    has not initialised the GPU), relay what they print -- rank 0's JSON line -- and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(launcher_command(n_ranks, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:  # stderr passes straight through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,17 +438,39 @@ def main():
                     help="engine mode: run the --workload shape (e.g. c4) instead of the reference's profiling shape e1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU work: start the ranks, rendezvous over gloo, print one line (tests the launch path on CPU)")
     ap.add_argument("--reference-quirk", action="store_true",
                     help="engine mode: reproduce the reference's stale-length upload (DESIGN.md deviation 2)")
     args = ap.parse_args()
     if args.dtype == "auto":
         args.dtype = "bf16" if args.workload == "c4" else "f32"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (plain `python bench.py --gpus N` "
+                         "starts the ranks itself; under torch.distributed.run pass --nproc-per-node N)")
+    if args.rehearse_launch:
+        # launcher -> N ranks -> rendezvous -> collective -> ONE line from rank 0, with no GPU work at all: what the
+        # CPU test of the self-launch path runs (tests/test_bench_launcher.py).  Never a measurement.
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = torch.tensor([1.0])
+        if world > 1:
+            dist.all_reduce(ranks)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks_seen": int(ranks.item()), "value": None}),
+                  flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     n_dev = torch.cuda.device_count()
     if local_rank >= n_dev and args.backend == "nccl":
         raise SystemExit(f"rank {local_rank} has no GPU ({n_dev} visible): one rank per GPU")
