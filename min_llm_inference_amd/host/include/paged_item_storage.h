@@ -39,6 +39,10 @@ public:
     void set_block_pos(int batch_id, int i_block, float*);
     TensorFloatPoint& get_page_table_device();
     int max_blocks_per_row() const { return static_cast<int>(width_); }  // extension: page-table width
+    // extension: the reference's stale-length upload (see set_reference_length_reset_quirk below), per manager so
+    // that several engines in one process do not change each other's admission behaviour
+    void set_length_reset_quirk(bool enabled) { length_reset_quirk_ = enabled; }
+    bool length_reset_quirk() const { return length_reset_quirk_; }
 
 private:
     TensorFloatPoint page_table_host;
@@ -46,6 +50,7 @@ private:
     std::list<BatchIdMemoryBlocksPair> used_blocks_;  // rows in admission order; the tail is preempted first
     size_t width_;                                    // n_sequence / PAGE_BLOCK_SIZE
     bool needs_sync_;
+    bool length_reset_quirk_;
     std::vector<long long> dirty_;                    // flat indices of entries changed since the last flush
 };
 
@@ -80,6 +85,8 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
 // The reference's paged insert_new_items uploads lengths_host without ever refreshing it from the device
 // (src/paged_item_storage.cpp:110-118), which resets every in-flight row to its insertion-time length
 // whenever a slot is free.  Default here: in-flight rows keep their true length.  Set to true to
-// reproduce the reference's behaviour (for measurement only).
+// reproduce the reference's behaviour (for measurement only).  The process-wide switch is only the value a
+// PagedAttentionsManager built afterwards starts with; PagedAttentionsManager::set_length_reset_quirk changes one
+// engine's behaviour without touching the others.
 void set_reference_length_reset_quirk(bool enabled);
 bool reference_length_reset_quirk();

@@ -142,7 +142,7 @@ struct mli_engine {
     }
 
     void start() {
-        set_reference_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
+        if (pages) pages->set_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
         get_global_throughput_counter().reset();
         get_global_throughput_counter().start_record();
         std::vector<int> all(cfg.n_batch);
@@ -157,7 +157,7 @@ struct mli_engine {
         if (started) throw std::runtime_error("pipelined run on an engine that has already been stepped");
         if (!paged() || cfg.n_forward_rounds != 1)
             throw std::runtime_error("the pipelined loop serves the paged kinds with n_forward_rounds = 1");
-        set_reference_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
+        pages->set_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
         get_global_throughput_counter().reset();
         started = true;
         iterations = run_paged_engine_pipelined(

@@ -1,5 +1,6 @@
 #include "inferencer.h"
 
+#include <cstring>
 #include <numeric>
 #include <stdexcept>
 #include <vector>
@@ -42,6 +43,13 @@ void run_paged_engine(ItemStorage& item_storage, ProcessingStorage& processing_s
                       MemoryBlockManager& memory_block_manager, PagedAttentionsManager& paged_attention_manager,
                       size_t n_batch_size, size_t n_sequence, int n_forward_rounds, Forward&& forward) {
     LoopTensors t(n_batch_size, n_sequence, {n_batch_size, static_cast<size_t>(n_forward_rounds)});
+    // Every slot starts empty on both sides.  The reference's first insert writes and uploads every slot; here an
+    // insert uploads only what changed, so the mirrors (pinned memory) and the device tensors (hipMalloc) must not
+    // start with whatever the allocations held: a forward over garbage lengths would chase garbage page pointers.
+    std::memset(t.lengths_host.data(), 0, n_batch_size * sizeof(int));
+    std::memset(t.inp_host.data(), 0, n_batch_size * n_sequence * sizeof(int));
+    t.lengths_device.copy_from(t.lengths_host);
+    t.inp_device.copy_from(t.inp_host);
     get_global_throughput_counter().start_record();
     std::vector<int> new_item_indices;
     {
@@ -51,6 +59,7 @@ void run_paged_engine(ItemStorage& item_storage, ProcessingStorage& processing_s
                                             processing_storage, memory_block_manager, paged_attention_manager,
                                             n_forward_rounds);
     }
+    throw_if_stuck(item_storage, processing_storage);  // no forward is launched for a queue nothing can be admitted from
     while (!is_done(item_storage, processing_storage)) {
         {
             Range r("forward");

@@ -175,7 +175,18 @@ void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t byt
     } else {
         wait_ready(s);
         wait_ready(dst);
-        HIP_CHECK(hipMemcpyAsync(d, f, bytes, kind, transfer_stream(dst->device)));
+        hipStream_t ts = transfer_stream(dst->device);
+        // The transfer stream is a blocking stream: it orders itself with the LEGACY default stream, which is where
+        // kernels run unless the engine has a private (non-blocking) compute stream.  With one, nothing is implicit:
+        // the copy must not start before the kernels queued so far have run (a D2H of their results, or an H2D into
+        // a buffer they still read), so the transfer stream first waits for that point of the compute stream.
+        if (hipStream_t cs = static_cast<hipStream_t>(runtime::compute_stream())) {
+            thread_local hipEvent_t ordered = nullptr;
+            if (ordered == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ordered, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ordered, cs));
+            HIP_CHECK(hipStreamWaitEvent(ts, ordered, 0));
+        }
+        HIP_CHECK(hipMemcpyAsync(d, f, bytes, kind, ts));
         mark_pending(dst);
     }
 }

@@ -9,7 +9,7 @@
 #include "utils.h"
 
 namespace {
-bool g_length_reset_quirk = false;
+bool g_length_reset_quirk = false;  // only the DEFAULT a newly built PagedAttentionsManager starts with
 }
 
 void set_reference_length_reset_quirk(bool enabled) { g_length_reset_quirk = enabled; }
@@ -40,8 +40,12 @@ void MemoryBlockManager::return_free_blocks(std::list<float*>&& blocks) {
 PagedAttentionsManager::PagedAttentionsManager(size_t max_batches, size_t n_sequence, size_t /*emb_dim*/)
     : page_table_host(std::vector<size_t>{max_batches, n_sequence / PAGE_BLOCK_SIZE}, DeviceType::HOST),
       page_table_device(std::vector<size_t>{max_batches, n_sequence / PAGE_BLOCK_SIZE}, DeviceType::DEVICE),
-      width_(n_sequence / PAGE_BLOCK_SIZE), needs_sync_(false) {
+      width_(n_sequence / PAGE_BLOCK_SIZE), needs_sync_(false), length_reset_quirk_(g_length_reset_quirk) {
     assert(n_sequence % PAGE_BLOCK_SIZE == 0);
+    // every entry starts null on both sides: a kernel that meets a row without pages skips it instead of
+    // dereferencing whatever the allocation held
+    std::fill(page_table_host.data(), page_table_host.data() + max_batches * width_, static_cast<float*>(nullptr));
+    page_table_device.copy_from(page_table_host);
 }
 
 std::list<BatchIdMemoryBlocksPair>& PagedAttentionsManager::get_used_block_list() { return used_blocks_; }
@@ -147,12 +151,13 @@ PagedAdmission admit_new_items(int* inp, int* lengths, int* new_idx, int max_bat
     std::vector<char> occupied(static_cast<size_t>(max_batch), 0);
     for (const BatchIdMemoryBlocksPair& row : pages.get_used_block_list()) occupied[row.first] = 1;
 
+    const bool quirk = pages.length_reset_quirk();
     PagedAdmission result;
     for (int slot = 0; slot < max_batch; ++slot) {
         if (occupied[slot]) {
             // in-flight row: its device length equals its host token count (see src/item_storage.cpp);
             // the reference leaves the stale insertion-time value here (quirk, off by default)
-            if (!g_length_reset_quirk)
+            if (!quirk)
                 lengths[slot] = static_cast<int>(processing_storage.get_token(slot).second.size());
             continue;
         }
@@ -160,7 +165,7 @@ PagedAdmission admit_new_items(int* inp, int* lengths, int* new_idx, int max_bat
         // (the decoder zeroes finished rows itself): nothing to upload for it.  A non-zero mirror means the row
         // left since then -- finished, or preempted with its device length still live -- so the lengths go up.
         // (The reference uploads whenever any slot is free; kept under the quirk switch.)
-        if (lengths[slot] != 0 || g_length_reset_quirk) result.lengths_changed = true;
+        if (lengths[slot] != 0 || quirk) result.lengths_changed = true;
         const int width = pages.max_blocks_per_row();
         const bool can_admit = pool.free_blocks_size() >= DEFAULT_INIT_NUM_BLOCKS && item_storage.new_count() > 0 &&
                                pool.free_blocks_size() >= std::min(width, ceil_div(item_storage.head_length() + n_forward_rounds, PAGE_BLOCK_SIZE));
@@ -194,7 +199,7 @@ std::vector<int> insert_new_items(TensorInt& inp_device, TensorInt& inp_host, Te
                                          n_sequence, item_storage, processing_storage, pool, pages, n_forward_rounds);
     upload_changed_rows(inp_device, inp_host, adm.slots, lengths_host.data(), n_sequence);
     if (adm.lengths_changed) lengths_device.copy_from(lengths_host);
-    if (!adm.slots.empty() || g_length_reset_quirk) new_items_indices_device.copy_from(new_items_indices_host);
+    if (!adm.slots.empty() || pages.length_reset_quirk()) new_items_indices_device.copy_from(new_items_indices_host);
     pages.maybe_flush_changes();
     return adm.slots;
 }

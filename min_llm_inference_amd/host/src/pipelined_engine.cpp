@@ -29,7 +29,7 @@ struct MarkerHandle {
 long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorage& processing_storage,
                                      MemoryBlockManager& pool, PagedAttentionsManager& pages, size_t n_batch_size,
                                      size_t n_sequence, const PagedForward& forward) {
-    if (reference_length_reset_quirk())
+    if (pages.length_reset_quirk())
         throw std::runtime_error("the pipelined engine does not reproduce the reference's length-reset quirk");
     const int B = static_cast<int>(n_batch_size), S = static_cast<int>(n_sequence);
     TensorInt inp_device({n_batch_size, n_sequence}, DeviceType::DEVICE), inp_host({n_batch_size, n_sequence}, DeviceType::HOST);
@@ -105,7 +105,16 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
         //    the tail of the admission list, and the victim's device length is zeroed before forward(step + 1)
         {
             Range r("allocate_or_free_memory_blocks_if_needed");
+            const size_t in_flight_before = processing_storage.size();
             allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2);
+            if (in_flight_before > 0 && processing_storage.size() == 0) {
+                // Every row was preempted, the last one by itself: with the whole pool to itself it still has no room
+                // for its next token.  Re-admitting it (its in-flight token is dropped, so it would fit again) and
+                // preempting it here again would repeat forever; the sequential loops report the same state as an
+                // error after their admission refuses the row (inferencer.cpp: throw_if_stuck).
+                mli::runtime::synchronize();
+                throw std::runtime_error("paged engine: the page pool is too small for the next queued item");
+            }
             idx.clear();
             val.clear();
             for (int b = 0; b < B; ++b) {

@@ -42,10 +42,17 @@ def workspace_for(n_batch, n_sequence, dim, device):
     """Caller-owned scratch for the split-sequence kernels (grown on demand, never inside a timed region)."""
     lib = load_library()
     need = int(lib.mli_attention_workspace_bytes(n_batch, n_sequence, dim))
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream), as the C++ side keys its scratch (host/src/memory_hip.cpp): the split-sequence
+    # kernels of two streams must not share partial sums.  A buffer that has to grow is replaced only after the
+    # stream that used the old one has drained.
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(index)
+    key = (index, stream.cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+        if ws is not None:
+            stream.synchronize()
+        ws = torch.zeros(max(need, 16), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws, need
 

@@ -146,6 +146,37 @@ int main() {
         std::printf("async-allocation tensor round trip: %d mismatches\n", bad);
         failures += bad != 0;
     }
+    // 7. start_paged_* with a pool that cannot serve the queue must throw, never launch a forward over undefined
+    //    lengths / page pointers and never spin: (a) the first insert admits nothing -- the pool is
+    //    below DEFAULT_INIT_NUM_BLOCKS; (b) the row is admitted but the pool cannot hold its growth, sequential and
+    //    pipelined loop alike.
+    for (int scenario = 0; scenario < 3; ++scenario) {
+        ItemStorage storage;
+        ProcessingStorage processing;
+        storage.add_new_item(IdTokensPair(0, std::vector<int>{1, 2, 3}));
+        const int n_blocks = scenario == 0 ? DEFAULT_INIT_NUM_BLOCKS - 1 : DEFAULT_INIT_NUM_BLOCKS + 1;
+        MemoryBlockManager pool(n_blocks, PAGE_BLOCK_SIZE * 3 * D);
+        PagedAttentionsManager pages(2, S, D);
+        // an embedding table whose EOF row is zero: greedy decoding never ends a row early, so it must outgrow the pool
+        TensorFloat emb_host({V, D}, DeviceType::HOST), emb_no_eof({V, D}, DeviceType::DEVICE);
+        emb_host.copy_from(emb);
+        std::memset(emb_host.data() + static_cast<size_t>(EOF_TOKEN_ID) * D, 0, D * sizeof(float));
+        emb_no_eof.copy_from(emb_host);
+        PagedAttentionInferenceModel model(PagedAttentionLayer(clone(wk), clone(wq), clone(wv), 2, D, S), PagedEncoderLayer(),
+                                           PagedDecoderLayer(2, V), 2, S, D, 1);
+        bool threw = false;
+        try {
+            if (scenario == 2)
+                start_paged_attention_inference_engine_pipelined(emb_no_eof, pos, storage, processing, pool, pages, model, 2, S);
+            else
+                start_paged_attention_inference_engine(emb_no_eof, pos, storage, processing, pool, pages, model, 2, S, 1);
+        } catch (const std::runtime_error& e) {
+            threw = std::strstr(e.what(), "too small") != nullptr;
+        }
+        std::printf("pool of %d pages, %s loop: %s\n", n_blocks, scenario == 2 ? "pipelined" : "sequential",
+                    threw ? "reported as too small" : "NOT reported");
+        failures += !threw;
+    }
     int mismatched = 0;
     for (const auto& kv : naive)
         if (paged[kv.first] != kv.second || gemm[kv.first] != kv.second || pipelined[kv.first] != kv.second) ++mismatched;

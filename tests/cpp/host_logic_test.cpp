@@ -224,9 +224,27 @@ static void test_paged_length_reset_quirk() {
     std::vector<int> result(B, 5), finished;
     result[3] = EOF_TOKEN_ID;
     decode_step(w, B, S, result, &finished);
-    set_reference_length_reset_quirk(true);
+    // a second engine in the same process, stepped in between: the switch belongs to ONE manager (a
+    // process-wide flag let one engine's start() change another engine's uploads mid-run)
+    PagedWorld other(B, S, D, 8 * B, lengths);
+    Buffers other_buf(B, S);
+    other.insert(other_buf);
+    std::vector<int> other_finished;
+    decode_step(other, B, S, result, &other_finished);
+    w.pages.set_length_reset_quirk(true);
+    CHECK(!other.pages.length_reset_quirk());
     w.insert(buf);
     CHECK_EQ(buf.len_d.data()[0], 10);  // stale insertion-time length, as src/paged_item_storage.cpp:110-118 uploads it
+    other.insert(other_buf);
+    CHECK_EQ(other_buf.len_d.data()[0], 11);  // the other engine still uploads the truth
+    w.pages.set_length_reset_quirk(false);
+    // the process-wide switch is the default of managers built afterwards, nothing more
+    set_reference_length_reset_quirk(true);
+    CHECK(!w.pages.length_reset_quirk());
+    {
+        PagedAttentionsManager later(B, S, D);
+        CHECK(later.length_reset_quirk());
+    }
     set_reference_length_reset_quirk(false);
     std::vector<int> result2(B, 5);
     result2[4] = EOF_TOKEN_ID;

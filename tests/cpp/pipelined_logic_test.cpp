@@ -188,6 +188,30 @@ int main() {
         CHECK(threw);
         std::printf("%s pool too small for any row: reported\n", threw ? "[ OK ]" : "[FAIL]");
     }
+    // A pool that admits a row (>= DEFAULT_INIT_NUM_BLOCKS pages) but cannot hold its growth, and no EOF: the row is
+    // the only one in flight when it runs out of pages.  ADVICE r1: the pipelined loop preempted it, dropped its
+    // in-flight token, re-admitted it at the same length and repeated that forever (> 5000 forwards, no progress);
+    // the sequential loop ends in "pool too small".  Both must report it, after a bounded number of forwards.
+    for (int n_blocks = DEFAULT_INIT_NUM_BLOCKS; n_blocks < 160 / PAGE_BLOCK_SIZE; ++n_blocks) {
+        World w(2, 160, n_blocks);
+        w.items.add_new_item(IdTokensPair(0, std::vector<int>{1, 2, 3}));
+        FakeModel model{2, 160, 0, std::vector<uint64_t>(2, 0), &w.pages};
+        bool threw = false;
+        try {
+            run_paged_engine_pipelined(w.items, w.processing, w.pool, w.pages, 2, 160,
+                                       [&](const TensorInt& inp, TensorInt& len, const TensorInt& idx, TensorInt& res, int n_new) {
+                                           if (model.launches > 1000) throw std::logic_error("no progress");
+                                           model.forward(inp, len, idx, res, n_new);
+                                       });
+        } catch (const std::runtime_error&) {
+            threw = true;
+        } catch (const std::logic_error&) {
+        }
+        CHECK(threw);
+        CHECK(model.launches <= n_blocks * PAGE_BLOCK_SIZE + 2);
+        std::printf("%s pool of %d pages for a row that needs %d: reported after %lld forwards\n", threw ? "[ OK ]" : "[FAIL]",
+                    n_blocks, 160 / PAGE_BLOCK_SIZE, model.launches);
+    }
     std::printf("%d failure(s)\n", g_failures);
     return g_failures != 0;
 }
