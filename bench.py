@@ -39,6 +39,8 @@ WORKLOADS = {
     "e1": ("paged", 1024, 2048, 128),
 }
 N_VOCAB = 1024
+SCAN_LEAN = "fused_decode_scan, lean (q.K^T + online softmax + softmax.V + in-kernel merge, one visit per page)"
+SCAN_FULL = "fused_decode_scan, materialising (raw scores written; merged by fused_decode_combine)"
 
 
 class Workload:
@@ -144,48 +146,66 @@ class Workload:
         self.attention()
         self.decoder()
 
-    # ---- the individual kernels, for the roofline pass ------------------------------------
-    def kernels_separate(self):
-        return self.kernels(fused_scan=False)
+    def rows(self, lo, hi):
+        """A view of batch rows [lo, hi): the same weights, pool and tables, row-indexed state sliced (rows are
+        independent in every kernel, so a slice is a complete smaller batch -- what a micro-batch or a rank owns)."""
+        import copy
+        v = copy.copy(self)
+        v.B = hi - lo
+        for name in ("lengths", "lengths0", "q_output", "qkt_output", "attention_result", "emb_score", "decoder_result",
+                     "new_idx", "page_table", "inp_embedding", "kt_cache", "v_cache"):
+            if hasattr(self, name):
+                setattr(v, name, getattr(self, name)[lo:hi])
+        v.lengths_host = self.lengths_host[lo:hi]
+        return v
 
-    def kernels(self, fused_scan=True):
+    # ---- what the layers / engines run: no scores or probabilities materialised, no emb_score ------------------
+    def lean_attention(self):
+        if self.layout == "paged":
+            ops.paged_attention_lean(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx,
+                                     self.q_output, self.attention_result, 0, self.S)
+        else:  # the contiguous layout keeps K transposed: its two passes need the score buffer between them
+            self.attention()
+
+    def fused_decoder(self):
+        if self.layout == "paged":
+            ops.paged_decoder_fused(self.attention_result, self.emb_table, self.wpe, self.page_table, self.lengths,
+                                    self.decoder_result, 0, self.dtype == "bf16")
+        else:
+            ops.decoder_fused(self.attention_result, self.emb_table, self.wpe, self.inp_embedding, self.lengths,
+                              self.decoder_result.view(-1))
+
+    def lean_step(self):
+        self.lean_attention()
+        self.fused_decoder()
+
+    # ---- the individual launches, for the roofline pass ------------------------------------
+    def kernels(self, lean=True):
+        """name -> callable for every launch of one decode step, in order.  lean = what the layers run."""
         w = self
         bf = self.dtype == "bf16"
-        if fused_scan and self.layout == "paged" and self.D <= 2048:
-            # the composition runs the single-pass scan (mli_decode_scan_paged): time its two launches apart
-            latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
-            return {
-                "get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: latest(
-                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
-                "fused_decode_scan (q.K^T + online softmax + softmax.V, one visit per page)": lambda: ops.decode_scan_paged(
-                    w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=1),
-                "fused_decode_combine": lambda: ops.decode_scan_paged(
-                    w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=2),
-            }
-        if self.dtype == "bf16":
-            return {
-                "get_latest_k_q_v_paged_bf16 (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention_bf16(
-                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
-                "qkt_paged_bf16": lambda: ops.launch_qkt_paged_attention_bf16(w.q_output, w.page_table, w.lengths, w.qkt_output),
-                "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
-                "softmax_v_paged_bf16": lambda: ops.launch_softmax_v_paged_attention_bf16(w.qkt_output, w.page_table,
-                                                                                          w.attention_result, w.lengths),
-            }
         if self.layout == "paged":
-            return {
-                "get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: ops.launch_get_latest_k_q_v_paged_attention(
-                    w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S),
-                "qkt_paged": lambda: ops.launch_qkt_paged_attention(w.q_output, w.page_table, w.lengths, w.qkt_output),
-                "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
-                "softmax_v_paged": lambda: ops.launch_softmax_v_paged_attention(w.qkt_output, w.page_table,
-                                                                                w.attention_result, w.lengths),
-            }
+            latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
+            k = {"get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: latest(
+                w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S)}
+            if lean:
+                k[SCAN_LEAN] = lambda: ops.decode_scan_paged(w.q_output, w.page_table, w.lengths, None, w.attention_result,
+                                                             bf, phases=7, n_sequence=w.S)
+                k["decoder head (logits GEMM with argmax epilogue + finalize)"] = w.fused_decoder
+            else:
+                k[SCAN_FULL] = lambda: ops.decode_scan_paged(w.q_output, w.page_table, w.lengths, w.qkt_output,
+                                                             w.attention_result, bf, phases=1)
+                k["fused_decode_combine (merge + probabilities)"] = lambda: ops.decode_scan_paged(
+                    w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=2)
+                k["decoder head (logits GEMM + argmax kernel, emb_score materialised)"] = w.decoder
+            return k
         return {
             "get_latest_kt_q_v (MFMA GEMM)": lambda: ops.launch_get_latest_kt_q_v(
                 w.inp_embedding, w.lengths, w.wk, w.wq, w.wv, w.kt_cache, w.v_cache, w.q_output),
             "qkt": lambda: ops.launch_qkt(w.q_output, w.kt_cache, w.lengths, w.qkt_output),
             "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
             "softmax_v": lambda: ops.launch_softmax_v(w.qkt_output, w.v_cache, w.attention_result, w.lengths),
+            "decoder head": w.fused_decoder if lean else w.decoder,
         }
 
     def algorithmic_bytes(self, lengths):
@@ -200,20 +220,35 @@ class Workload:
         latest = live * D * (3 * e + 4) + 3 * D * D * e + B * 4 + (8 * live if self.layout == "paged" else 0)
         step = (2 * kv_one + live * (3 * D * e + D * 4) + 3 * D * D * e + B * 4 + ptrs)
         scan = 2 * kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4   # K + V + q in, raw scores out
-        return {"qkt": qkt, "softmax_v": sv, "scan": scan, "get_latest": latest, "step": step}
+        scan_lean = 2 * kv_one + 2 * live * D * 4 + ptrs + B * 4             # K + V + q in, attention_result out
+        return {"qkt": qkt, "softmax_v": sv, "scan": scan, "scan_lean": scan_lean, "get_latest": latest, "step": step}
 
 
-def time_kernel(fn, reps):
+def time_kernel(fn, reps, batch=1):
+    """Average duration of fn's launches in ms, HIP events on the stream they are launched on (torch's current
+    stream).  batch > 1: `batch` calls are captured into one hipGraph and replayed, so that a launch of a few
+    microseconds is not timed at the rate Python can issue it."""
     fn()
-    torch.cuda.synchronize()
+    st = torch.cuda.current_stream()
+    st.synchronize()
+    g = None
+    if batch > 1:
+        g = ops.StepGraph(lambda: [fn() for _ in range(batch)])
+        run, n, per = g.launch, max(1, reps // batch), batch
+    else:
+        run, n, per = fn, reps, 1
+    run()
+    st.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps  # ms, on the stream the kernels were launched on
+    e0.record(st)
+    for _ in range(n):
+        run()
+    e1.record(st)
+    st.synchronize()
+    if g is not None:
+        g.close()
+    return e0.elapsed_time(e1) / (n * per)
 
 
 def measure_copy_gbs(dev):
@@ -222,6 +257,7 @@ def measure_copy_gbs(dev):
     b = torch.empty(n, device=dev)
     a.uniform_()
     ms = time_kernel(lambda: ops.stream_copy(a, b), 10)
+    del a, b
     return 2 * n * 4 / (ms * 1e-3) / 1e9
 
 
@@ -307,7 +343,7 @@ def large_gemm_report(dev):
         try:
             w = Workload("e1", dev, 0xE1, headroom=8, dtype=dt)
             fn = [v for k, v in w.kernels().items() if k.startswith("get_latest")][0]
-            ms = time_kernel(fn, 100)
+            ms = time_kernel(fn, 100, batch=10)
             tf = 2.0 * w.B * w.D * 3 * w.D / (ms * 1e-3) / 1e12
             out[dt] = {"avg_launch_ms": ms, "achieved": tf, "peak": MFMA_PEAK_TFLOPS[dt], "frac": tf / MFMA_PEAK_TFLOPS[dt]}
             del w
@@ -325,8 +361,10 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
-    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan"}[which]
-    hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k]
+    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan", "scan_lean": "fused_decode_scan"}[which]
+    # the scan kernel's last template argument says whether it writes the raw scores: "..., true>" / "..., false>"
+    tail = {"scan": ", true>", "scan_lean": ", false>"}.get(which, "")
+    hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and k.endswith(tail)]
     return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
 
@@ -425,6 +463,12 @@ def main():
                          "auto = what BASELINE.json names for the workload: bf16 for c4, fp32 for c2/c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (short runs of the other BASELINE configurations and the engine workload)")
+    ap.add_argument("--config-steps", type=int, default=50, help="timed steps of every run in the `configs` block")
+    ap.add_argument("--materialising", action="store_true",
+                    help="time the reference's launch sequence (scores, probabilities and emb_score written) as the "
+                         "headline instead of the lean composition the layers run")
     ap.add_argument("--mode", choices=["step", "engine"], default="step",
                     help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
     ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16"], default="paged_gemm",
@@ -515,38 +559,128 @@ def main():
             dist.destroy_process_group()
         return
 
+    side = torch.cuda.Stream(device=dev)  # a real stream: the legacy default stream cannot be captured into a graph
+    with torch.cuda.stream(side):
+        out = run_step_bench(args, rank, world, dev, dist)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()  # ranks leave together (rank 0 may still have been in its roofline pass)
+        dist.destroy_process_group()
+
+
+def timed_steps(wl, step, steps, warmup, world, dist, gather=None):
+    """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+    def one():
+        if gather is not None:
+            # the decoder writes this step's tokens into a buffer whose previous gather has completed; the gather of
+            # this step (the path's only exchange: 4 KiB of token ids per rank at B=1024) then runs on RCCL's stream
+            # beside the next step's kernels
+            wl.decoder_result = gather.buffer().view(wl.B, 1)
+        step()
+        if gather is not None:
+            gather()
+
+    for _ in range(warmup):
+        one()
+    if gather is not None:
+        gather.wait()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    # every row must still be live, otherwise "tokens" would over-count
+    grown = (wl.lengths - wl.lengths0).cpu().numpy()
+    assert (grown == steps + warmup).all(), "a row finished during the timed region"
+    return elapsed
+
+
+def roofline_report(wl, workload, dtype, lengths_now, ms_per_step, reps, lean=True):
+    """Per-launch times of one decode step (HIP events on the launch stream; launches of a few microseconds are
+    replayed from a graph of 10 so that Python's launch rate is not what gets timed) and the roofline of the
+    dominant kernel: its ALGORITHMIC bytes / its average launch duration against the 8 TB/s HBM peak."""
+    alg = wl.algorithmic_bytes(lengths_now)
+    L0 = wl.lengths.clone()
+    times = {}
+    for name, fn in wl.kernels(lean=lean).items():
+        big = name.startswith("fused_decode_scan") and wl.B * wl.S >= (1 << 21)
+        times[name] = time_kernel(fn, max(10, reps), batch=1 if big else 10)
+        wl.lengths.copy_(L0)  # the decoder head advances the lengths
+    torch.cuda.synchronize()
+    if wl.layout == "paged":
+        key_of = {"scan_lean" if lean else "scan": SCAN_LEAN if lean else SCAN_FULL}
+    else:
+        key_of = {"qkt": "qkt", "softmax_v": "softmax_v"}
+    dom = max(key_of, key=lambda k: times[key_of[k]])
+    ms = times[key_of[dom]]
+    achieved = alg[dom] / (ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(workload, dom, wl.layout, dtype)
+    return {
+        "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms, "kernel_ms": times,
+        "sum_of_launches_ms": sum(times.values()),
+        "step_algorithmic_bytes": alg["step"],
+        "step_gbs": alg["step"] / (ms_per_step * 1e-3) / 1e9,
+        "step_frac": alg["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }, times
+
+
+def side_config(name, dtype, dev, steps, warmup):
+    """One of the other BASELINE configurations as a short single-GPU step run (the `configs` block of the line)."""
+    cfg_index = sorted(WORKLOADS).index(name) + 1
+    wl = Workload(name, dev, 0x5EED0000 + cfg_index * 16, headroom=steps + warmup + 8, dtype=dtype)
+    wl.lean_step()
+    wl.lengths.copy_(wl.lengths0)
+    elapsed = timed_steps(wl, wl.lean_step, steps, warmup, 1, None)
+    ms = elapsed / steps * 1e3
+    roof, _ = roofline_report(wl, name, dtype, wl.lengths.cpu().numpy(), ms, max(20, steps // 2))
+    r = {"workload": f"{name}: {wl.layout} KV decode step, {wl.B} rows, emb_dim {wl.D}, max_seq {wl.S}, "
+                     f"{'bf16 pages and weights' if dtype == 'bf16' else 'fp32'}, lean composition",
+         "dtype": dtype, "steps": steps, "warmup": warmup, "value": wl.B * steps / elapsed, "unit": "tokens/s",
+         "ms_per_step": ms, "roofline": roof}
+    del wl
+    torch.cuda.empty_cache()
+    return r
+
+
+def engine_config(args, dev):
+    """The reference's own profiling workload end to end (README.md:54-82: 123 284 tok/s on an unnamed NVIDIA GPU),
+    in a child process so that the engine's allocations and host threads never share this process's timed region."""
+    import subprocess
+    out = {}
+    for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_pipelined", ["--pipelined"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "engine", "--gpus", "1", *extra]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            out[label] = {"value": d["value"], "unit": d["unit"], "vs_readme_123284": d["vs_baseline"],
+                          "iterations": d["steps"], "seconds": d["config"]["seconds"], "workload": d["config"]["workload"]}
+        except Exception as e:  # a side measurement never takes the bench line down
+            out[label] = {"error": str(e)[:300]}
+    return out
+
+
+def run_step_bench(args, rank, world, dev, dist):
     cfg_index = sorted(WORKLOADS).index(args.workload) + 1
     wl = Workload(args.workload, dev, 0x5EED0000 + cfg_index * 16 + rank, headroom=args.steps + args.warmup + 8,
                   dtype=args.dtype)
     from min_llm_inference_amd.sharding import TokenGather
     gather = TokenGather(wl.B, world, dev)
-
-    def step():
-        # the decoder writes this step's tokens into a buffer whose previous gather has completed; the gather of
-        # this step (the path's only exchange: 4 KiB of token ids per rank at B=1024) then runs on RCCL's stream
-        # beside the next step's kernels
-        wl.decoder_result = gather.buffer().view(wl.B, 1)
-        wl.step()
-        gather()
-
-    for _ in range(args.warmup):
-        step()
-    gather.wait()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    gather.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    # every row must still be live, otherwise "tokens" below would over-count
-    grown = (wl.lengths - wl.lengths0).cpu().numpy()
-    assert (grown == args.steps + args.warmup).all(), "a row finished during the timed region"
+    lean = not args.materialising
+    step = wl.lean_step if lean else wl.step
+    step()                                  # per-stream workspaces are allocated outside the timed region
+    wl.lengths.copy_(wl.lengths0)
+    elapsed = timed_steps(wl, step, args.steps, args.warmup, world, dist, gather)
     tokens = torch.tensor([float(wl.B * args.steps)], device=dev)
     tmax = torch.tensor([elapsed], device=dev)
     if world > 1:
@@ -554,7 +688,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     total_tokens = float(tokens.item())
-
+    form = ("lean composition: what the layers run -- no scores / probabilities / emb_score materialised, chunks merged "
+            "inside the scan launch" if lean else
+            "materialising composition: the reference's launch sequence, qkt_output probabilities and emb_score written")
     out = {
         "metric": "decode tokens/sec (whole node) on synthetic batch",
         "value": total_tokens / elapsed,
@@ -571,47 +707,54 @@ def main():
         "config": {
             "workload": f"{args.workload}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
                         f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[{wl.S // 4},{int(wl.lengths_host.max())}], "
-                        f"{'bf16 pages and weights, fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}",
+                        f"{'bf16 pages and weights, fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}; {form}",
             "rows_per_gpu": wl.B, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
             "mean_length": float(wl.lengths_host.mean()),
             "parallelism": f"row-sharded replicas x{world}, all-gather of token ids",
         },
     }
-
     if rank == 0 and not args.no_roofline:
         lengths_now = wl.lengths.cpu().numpy()
-        alg = wl.algorithmic_bytes(lengths_now)
-        times = {}
-        for name, fn in wl.kernels().items():
-            times[name] = time_kernel(fn, max(10, args.steps))
-        wl.lengths.copy_(torch.from_numpy(lengths_now).to(dev))
-        if any(k.startswith("fused_decode_scan") for k in times):
-            key_of = {"scan": [k for k in times if k.startswith("fused_decode_scan")][0]}
-        else:
-            key_of = {"qkt": [k for k in times if k.startswith("qkt")][0],
-                      "softmax_v": [k for k in times if k.startswith("softmax_v")][0]}
-        dom = max(key_of, key=lambda k: times[key_of[k]])
-        ms = times[key_of[dom]]
-        achieved = alg[dom] / (ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload, dom, wl.layout, args.dtype)
-        out["roofline"] = {
-            "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms,
-            "kernel_ms": times,
-            "projection_gemm": gemm_report(wl, lengths_now, times),
-            "projection_gemm_d2048": large_gemm_report(dev),
-            "step_algorithmic_bytes": alg["step"],
-            "step_gbs": alg["step"] / (out["ms_per_step"] * 1e-3) / 1e9,
-            "measured_copy_gbs": measure_copy_gbs(dev),
-        }
+        reps = max(10, args.steps)
+        roof, times = roofline_report(wl, args.workload, args.dtype, lengths_now, out["ms_per_step"], reps, lean=lean)
+        roof["projection_gemm"] = gemm_report(wl, lengths_now, times)
+        out["roofline"] = roof
+        if world == 1 and wl.layout == "paged":
+            # the other form of the same step, same state, same run: K steps each, plus its scan / combine launches
+            other = wl.step if lean else wl.lean_step
+            other()
+            wl.lengths.copy_(wl.lengths0)
+            t_other = timed_steps(wl, other, args.steps, args.warmup, 1, None)
+            o_roof, _ = roofline_report(wl, args.workload, args.dtype, wl.lengths.cpu().numpy(),
+                                        t_other / args.steps * 1e3, reps, lean=not lean)
+            mine = {"ms_per_step": out["ms_per_step"], "value": out["value"], "scan_frac": roof["frac"],
+                    "scan_ms": roof["avg_launch_ms"]}
+            theirs = {"ms_per_step": t_other / args.steps * 1e3, "value": wl.B * args.steps / t_other,
+                      "scan_frac": o_roof["frac"], "scan_ms": o_roof["avg_launch_ms"], "kernel_ms": o_roof["kernel_ms"]}
+            out["modes"] = {"lean": mine if lean else theirs, "materialising": theirs if lean else mine,
+                            "note": "attention_result, tokens, lengths and pages are bit-identical between the two forms "
+                                    "(tests/test_lean_path_gpu.py); `value` is the form config.workload names"}
+        if world == 1:
+            roof["projection_gemm_d2048"] = large_gemm_report(dev)
+            roof["measured_copy_gbs"] = measure_copy_gbs(dev)
+    import types
+    meta = types.SimpleNamespace(B=wl.B, D=wl.D, S=wl.S, lengths_host=wl.lengths_host)  # all cpu_baseline needs
+    del wl
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_configs:
+        cfgs = {}
+        for name, dtype in (("c2", "f32"), ("c3", "f32"), ("c4", "f32" if args.dtype == "bf16" else "bf16")):
+            if name == args.workload and dtype == args.dtype:
+                continue
+            try:
+                cfgs[f"{name}_{dtype}"] = side_config(name, dtype, dev, args.config_steps, 10)
+            except Exception as e:
+                cfgs[f"{name}_{dtype}"] = {"error": str(e)[:300]}
+        cfgs["engine"] = engine_config(args, dev)
+        out["configs"] = cfgs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()  # ranks leave together (rank 0 may still have been in its roofline pass)
-        dist.destroy_process_group()
+        out["cpu_baseline"] = cpu_baseline(meta)
+    return out
 
 
 if __name__ == "__main__":

@@ -43,9 +43,16 @@ extern "C" {
 int mli_abi_version(void);
 
 /* Bytes of device scratch the split-sequence kernels need for a problem of this size
- * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention): per-chunk softmax statistics
- * followed by the split-sequence partial sums.  Never 0 for a valid shape. */
+ * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention): per-chunk softmax statistics,
+ * the split-sequence partial sums, and -- in a fixed 64 KiB region at the front, so that calls of different shapes can
+ * share one buffer -- one arrival counter per batch row for the lean single-pass scan.  Never 0 for a valid shape.
+ * The owner zero-fills that region ONCE after allocating the buffer (mli_attention_workspace_init); every entry point
+ * leaves the counters zero on return, so nothing is re-initialised per call (nor under graph replay).  One workspace
+ * serves one stream at a time. */
 size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim);
+/* Zero-fills the arrival counters at the front of a freshly allocated workspace (the first 64 KiB; a buffer that was
+ * allocated zero-filled needs no call).  Stream-ordered; once per allocation, not per call. */
+int mli_attention_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Contiguous ("naive") KV-cache path.
@@ -171,11 +178,25 @@ int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* 
                                         int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
                                         int n_decoder_results, int i_decoder, void* stream);
 
+/* LEAN paged composition -- what PagedAttention*Layer::forward runs.  The reference's paged_attention also leaves the
+ * softmax probabilities in its qkt_output scratch (paged_attention.h:17-25), which nothing downstream reads
+ * (src/layers.cpp:84-100 passes attention_result on, qkt_output stays in the layer).  This form computes the same
+ * attention_result (bit-identical to mli_paged_attention[_bf16]) without materialising scores or probabilities:
+ * fill (n_new_items rows) -> latest -> single-pass scan whose chunk results are merged inside the scan launch by the
+ * workgroup that completes a row.  elem_bf16 selects the page / weight element type (0 = float, 1 = mli_bf16). */
+int mli_paged_attention_lean(void* const* page_table, const int* lengths,
+                             const void* wk, const void* wq, const void* wv, const int* new_batch_idx,
+                             float* q_output, float* attention_result,
+                             int n_batch, int n_sequence, int emb_dim, int n_new_items, int elem_bf16,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* The single-pass scan the paged compositions run after the projection (scores + masked softmax + softmax.V in
  * one visit per page; what A10 -> A4 -> A11 of SURVEY 8(a) compute together).  Inputs: q_output from
  * mli_get_latest_k_q_v_paged[_bf16]; outputs: qkt_output (probabilities, zero tail) and attention_result.
  * elem_bf16 selects the page element type; phases: 1 = scan kernel only, 2 = combine kernel only, 3 = both
- * (1 and 2 exist so the two launches can be timed apart).  Rows of up to two 16-byte lane loads (fp32 <= 512,
+ * (1 and 2 exist so the two launches can be timed apart); + 4 = lean mode: qkt_output is neither read nor written
+ * (may be NULL) and the scan merges every row's chunks itself, so 5 = 7 = the whole job in ONE launch (6 = nothing;
+ * with mli_tune("scan_merge", 0) the merge stays a second, slimmer launch and 5 / 6 time the two apart).  Rows of up to two 16-byte lane loads (fp32 <= 512,
  * bf16 <= 1024) give every wave whole pages; wider rows (fp32 <= 2048, bf16 <= 4096) are split across the four
  * waves of a workgroup.  Returns MLI_ERR_BAD_ARG beyond that: use the separate entry points then. */
 int mli_decode_scan_paged(const float* q_output, const void* const* page_table, const int* lengths,
@@ -210,6 +231,41 @@ int mli_paged_decoder_multi_rounds(const float* batch_result, const float* emb_t
                                    int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
                                    int n_decoder_results, int i_decoder, void* stream);
 
+/* Decoder head with the argmax as the logits GEMM's EPILOGUE: emb_score[n_batch, n_vocab] is
+ * never materialised.  Every 64-column tile of the product leaves one (max, lowest index of the max) pair per row in
+ * `scratch` (mli_decoder_scratch_bytes), a one-wave-per-row kernel picks the row's token from those pairs, updates the
+ * length and writes the next input embedding.  Tokens, lengths and embeddings are identical to mli_decoder /
+ * mli_paged_decoder_multi_rounds[_bf16] (same fp32 products, same argmax order: larger value, then lower index) --
+ * those stay for callers that want emb_score (the reference's decoder tests compare it).  What *DecoderLayer::forward
+ * runs.  Replaces launch_decoder / launch_paged_attention[_cublas]_decoder_multi_rounds (decoder.h:19-37). */
+size_t mli_decoder_scratch_bytes(int n_batch, int n_vocab);
+int mli_decoder_fused(const float* batch_result, const float* emb_table, const float* wpe_table,
+                      float* inp_embedding, int* lengths, int* decoder_result,
+                      int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                      void* scratch, size_t scratch_bytes, void* stream);
+int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, const float* wpe_table,
+                            void* const* page_table, int* lengths, int* decoder_result,
+                            int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                            int n_decoder_results, int i_decoder, int elem_bf16,
+                            void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * hipGraph capture of a decode step.  No entry point above allocates or synchronises, so any sequence of them issued
+ * on one (non-default) stream between begin and end becomes a graph; replaying it costs one host call instead of one
+ * per kernel.  A decode step with n_new_items == 0 is replay-safe: its launches depend on device state (lengths,
+ * page table, pages) only through pointers, never through host-side values.  What the engines' forward() replays
+ * (reference loop: src/inference_model.cpp:56-81).
+ * ---------------------------------------------------------------------------------- */
+int mli_graph_begin_capture(void* stream);                      /* stream must not be the legacy default stream */
+int mli_graph_end_capture(void* stream, void** graph_exec_out); /* ends the capture and instantiates it */
+int mli_graph_launch(void* graph_exec, void* stream);
+/* `waiter` does not run anything queued after this call before everything queued on `signaller` so far has run (an
+ * event recorded on one stream and waited for on the other).  Inside a capture it adds a dependency edge -- and pulls
+ * `waiter` into the capture --, which is how a captured step forks into parallel branches (e.g. two micro-batches of
+ * the batch rows: one half's memory-bound scan beside the other half's latency-bound GEMMs) and joins again. */
+int mli_stream_wait_stream(void* waiter, void* signaller);
+int mli_graph_destroy(void* graph_exec);
+
 /* ------------------------------------------------------------------------------------
  * Test / measurement support (not on the reference's product path).
  * ---------------------------------------------------------------------------------- */
@@ -229,8 +285,12 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
  *                      once for K and V, online softmax) when emb_dim fits (fp32 <= 2048, bf16 <= 4096);
  *                      0 = separate q.K^T / softmax / softmax.V passes
- *   "scan_partial_last" 1 (default) = the single-pass scan runs full chunks first and every row's partial chunk in a
- *                      last grid row (shorter tail), 0 = plain chunk order
+ *   "scan_partial_last" 1 (default) = the single-pass scan runs full chunks first and every row's remainder behind
+ *                      them, cut into pieces of "scan_tail_tokens" tokens (what is still running when the queue runs
+ *                      dry is short), 0 = plain chunk order
+ *   "scan_tail_tokens" 0 (default) = 128, else a power of two in [64, chunk]: the size of those pieces
+ *   "scan_merge"       (lean mode) 1 (default) = the workgroup that completes a row merges its chunks inside the scan
+ *                      launch, 0 = a separate combine launch; bit-identical results
  *   "scan_dynamic_items" 1 = the single-pass scan hands its (row, chunk) items out through a ticket counter (balances
  *                      the XCDs on ragged lengths; the counter reset costs what it gains), 0 (default) = by grid position
  *   "fused_softmax"    (separate-pass form only) 1 = the compositions fold the masked softmax into the qkt / softmax.V kernels, 0 = three

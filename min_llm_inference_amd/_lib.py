@@ -42,6 +42,7 @@ _Z = ctypes.c_size_t
 SIGNATURES = {
     "mli_abi_version": [],
     "mli_attention_workspace_bytes": [_I, _I, _I],
+    "mli_attention_workspace_init": [_P, _Z, _P],
     "mli_fill_new_kt_v_cache": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mli_get_latest_kt_q_v": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mli_qkt": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -61,6 +62,15 @@ SIGNATURES = {
     "mli_paged_attention_encoder_bf16": [_P] * 6 + [_I] * 4 + [_P],
     "mli_paged_decoder_multi_rounds_bf16": [_P] * 7 + [_I] * 6 + [_P],
     "mli_decode_scan_paged": [_P] * 5 + [_I] * 5 + [_P, _Z, _P],
+    "mli_paged_attention_lean": [_P] * 8 + [_I] * 5 + [_P, _Z, _P],
+    "mli_decoder_scratch_bytes": [_I, _I],
+    "mli_decoder_fused": [_P] * 6 + [_I] * 4 + [_P, _Z, _P],
+    "mli_paged_decoder_fused": [_P] * 6 + [_I] * 7 + [_P, _Z, _P],
+    "mli_graph_begin_capture": [_P],
+    "mli_graph_end_capture": [_P, ctypes.POINTER(ctypes.c_void_p)],
+    "mli_graph_launch": [_P, _P],
+    "mli_stream_wait_stream": [_P, _P],
+    "mli_graph_destroy": [_P],
     "mli_inference_optimized_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_paged_attention_encoder": [_P] * 6 + [_I] * 4 + [_P],
     "mli_decoder": [_P] * 7 + [_I] * 4 + [_P],
@@ -96,7 +106,7 @@ ENGINE_SIGNATURES = {
     "mli_engine_get_finished": [_P, _I, _IP, _P, _I, _IP],
     "mli_engine_last_error": [],
 }
-_RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
+_RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_decoder_scratch_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
              "mli_engine_destroy": None}
 
 

@@ -71,6 +71,13 @@ struct ElemBF16 {
     }
 };
 
+// number of (m, l, partial) triples a row of length L produces: full chunks + pieces of the remainder
+__host__ __device__ __forceinline__ int row_items(int L, int ct, int tail) {
+    if (tail == 0) return (L + ct - 1) / ct;
+    const int nf = L / ct;
+    return nf + (L - nf * ct + tail - 1) / tail;
+}
+
 // TBR = rows per load batch, MINW = waves per SIMD the register allocator must leave room for
 // WAVES = waves per workgroup (each wave owns whole pages; 1 = every wave is its own scheduling unit)
 // DS = false: a wave owns whole pages (rows of up to NJ * 64 lane loads) and the waves are merged at the end;
@@ -78,11 +85,22 @@ struct ElemBF16 {
 //      of each row; the 16 partial scores of a page are exchanged through LDS (one barrier per page, double
 //      buffered), after which all waves hold identical softmax state and accumulate their own slice of the output
 //      -- perfect balance between the waves however few pages a row has, and no end-of-kernel merge.
-template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false>
+// SCORES = true: the reference's contract for the composition -- raw scores go to qkt_output (the combine kernel or
+//      the direct path turns them into probabilities with a zero tail).  SCORES = false ("lean" mode, what the layers
+//      and engines run): qkt_output is never touched, the only outputs are attention_result and, between the two
+//      launches, the per-chunk (max, sum, partial output) triples.
+// arrivals != nullptr (lean mode, more than one chunk per row): no combine launch.  Every workgroup publishes its
+//      triple write-through (sc1 stores, drained, then one agent-scope add on the row's arrival counter); the
+//      workgroup whose add completes the row merges the row's triples in chunk order -- the same expressions in the
+//      same order as fused_decode_combine_kernel, so the result is bit-identical to the two-launch form -- and puts
+//      the counter back to zero for the next launch.  (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload +
+//      every storing wave's vmcnt(0) + barrier + counter add; consumer: agent acquire + vmcnt(0) + barrier, then loads.)
+template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false, bool SCORES = true>
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
-    float* __restrict__ qkt, float* __restrict__ out, float2* __restrict__ ml, float* __restrict__ partial,
-    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, unsigned* __restrict__ ticket, int partial_last) {
+    float* __restrict__ qkt, float* __restrict__ out, float2* ml, float* partial,
+    int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, unsigned* __restrict__ ticket, int tail,
+    int slots, unsigned* arrivals) {
     constexpr int EPL = E::EPL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
@@ -94,8 +112,12 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     // round-robin by grid position, so the static form gives every XCD a fixed eighth of the rows -- with ragged
     // lengths the XCDs' totals differ by +-10 % and the slowest one sets the kernel time (tools/scan_trace.py: last
     // workgroup of an XCD at 615..701 us); tickets let the XCDs that run ahead take more items.
-    int b = blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear grid position, i.e. by blockIdx.x % 8 (n_batch is a
+    // multiple of 8 in every configuration that fills the chip).  Rotating the row index by the chunk index spreads
+    // the chunks of one row over the XCDs, so every XCD streams a mix of all rows instead of a fixed eighth of them
+    // whose total length differs from the others' by +-10 % (tools/scan_trace.py: XCDs done at 615 .. 701 us).
     int c = blockIdx.y;
+    int b = (int)((blockIdx.x + (unsigned)c) % gridDim.x);
     if (ticket != nullptr) {
         __shared__ unsigned item_sh;
         if (threadIdx.x == 0) item_sh = atomicAdd(ticket, 1u);
@@ -115,30 +137,39 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
 #endif
     MLI_TRACE(0);
     const int L = min(lengths[b], S);
-    if (partial_last) {
-        // Largest items first: grid rows 0 .. nchunk-1 run only the FULL chunks, one extra grid row at the end runs each
-        // row's partial chunk.  In plain chunk order the last workgroups to start are often full ones, and the launch
-        // ends with a long tail at a fraction of the bandwidth (tools/scan_trace.py).
-        if (c == nchunk_max) {
-            if (L % ct == 0) return;            // no partial chunk (covers the empty row)
-            c = L / ct;
-        } else if ((c + 1) * ct > L) {
-            return;                             // empty, or the partial chunk (the extra grid row takes it)
+    if (arrivals != nullptr && L == 0) {
+        // in-kernel merge: no workgroup arrives for an empty row, so its zero result is written here, once
+        if (blockIdx.y == 0) for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) out[(int64_t)b * D + i] = 0.f;
+        return;
+    }
+    // Items of a row, in token order: its full chunks, then (tail > 0) the remainder cut into pieces of `tail` tokens.
+    // Largest items first: grid rows 0 .. nchunk-1 run only the FULL chunks, the grid rows behind them the pieces of
+    // every row's remainder.  In plain chunk order the last workgroups to start are often full ones and the launch
+    // ends with a long stretch at a fraction of the bandwidth (tools/scan_trace.py); with the pieces last, what is
+    // still running when the queue runs dry is at most `tail` tokens long.
+    int s0 = c * ct, s1 = min(s0 + ct, L);
+    if (tail) {
+        const int nf = L / ct;
+        if (c < nchunk_max) {
+            if (c >= nf) return;                // empty, or part of the remainder (the grid rows behind take it)
+        } else {
+            s0 = nf * ct + (c - nchunk_max) * tail;
+            if (s0 >= L) return;                // (covers the empty row)
+            s1 = min(s0 + tail, L);
+            c = nf + (c - nchunk_max);          // its slot among the row's items
         }
     }
-    const int s0 = c * ct;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     float* qkt_row = qkt + (int64_t)b * S;
 
     if (s0 >= L) {
         if (direct) {  // single-chunk problem: this workgroup owns the whole (empty) row
-            for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = 0.f;
+            if (SCORES) for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = 0.f;
             for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) out[(int64_t)b * D + i] = 0.f;
         }
         return;
     }
-    const int s1 = min(s0 + ct, L);
     const int ntok = s1 - s0;
     const int npages = (ntok + kPage - 1) / kPage;
     for (int i = threadIdx.x; i < npages; i += (WAVES * kWave))
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
                     }
                     const bool valid = slot < nt;
                     const float score = tot / scale;
-                    if (valid && (lane & 3) == 0 && (!DS || wave == 0))
+                    if (SCORES && valid && (lane & 3) == 0 && (!DS || wave == 0))
                         qkt_row[s0 + pi * kPage + slot] = score;  // raw; normalised later
                     // online softmax update
                     const float pm = wave_max(valid ? score : -INFINITY);
@@ -297,62 +328,148 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     }
     MLI_TRACE(3);
 
+    // ---- the chunk's result: (m, l) and the un-normalised partial output row ----
+    // DS: every wave already holds the chunk's (max, sum) and its own slice of the output.
+    // otherwise: the waves (each owns whole pages) are merged in wave order through LDS.
+    const bool publish = arrivals != nullptr;  // lean mode, several chunks per row: in-kernel merge by the last arriver
+    float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * slots + c) * D;
+    float m, l;
     if constexpr (DS) {
-        // every wave holds the chunk's (max, sum) and its own slice of the output
-        float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * nchunk_max + c) * D;
+        m = run_m;
+        l = run_l;
         const float norm = direct ? 1.f / run_l : 1.f;
+        // write-through (sc1) stores when another workgroup will read the row back inside this launch
+        const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(o, 0, D * (int)sizeof(float), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (!live[j]) continue;
             const int u = wave * NJ * kWave + lane + j * kWave;
 #pragma unroll
-            for (int e = 0; e < EPL; e += 4)
-                *reinterpret_cast<float4*>(o + (int64_t)u * EPL + e) =
-                    make_float4(acc[j][e] * norm, acc[j][e + 1] * norm, acc[j][e + 2] * norm, acc[j][e + 3] * norm);
+            for (int e = 0; e < EPL; e += 4) {
+                const float4 v = make_float4(acc[j][e] * norm, acc[j][e + 1] * norm, acc[j][e + 2] * norm, acc[j][e + 3] * norm);
+                if (publish) {
+                    fu_u32x4 raw;
+                    raw.x = __float_as_uint(v.x); raw.y = __float_as_uint(v.y); raw.z = __float_as_uint(v.z); raw.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, orow, (u * EPL + e) * (int)sizeof(float), 0, 16);
+                } else {
+                    *reinterpret_cast<float4*>(o + (int64_t)u * EPL + e) = v;
+                }
+            }
         }
-        if (direct) {
-            __syncthreads();  // wave 0's raw scores are visible to the workgroup after the barrier
-            const float inv_l = 1.f / run_l;
-            for (int i = threadIdx.x; i < S; i += (WAVES * kWave))
-                qkt_row[i] = i < L ? expf(qkt_row[i] - run_m) * inv_l : 0.f;
-        } else if (threadIdx.x == 0) {
-            ml[(int64_t)b * ml_per_row + c] = make_float2(run_m, run_l);
+    } else {
+        constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes
+        if (lane == 0) wave_ml[wave] = make_float2(run_m, run_l);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) red[wave * kRowF + (j * kWave + lane) * EPL + e] = acc[j][e];
+        __syncthreads();
+        m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) m = fmaxf(m, wave_ml[w].x);
+        float wsc[WAVES];
+        l = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            wsc[w] = wave_ml[w].x == -INFINITY ? 0.f : expf(wave_ml[w].x - m);
+            l += wave_ml[w].y * wsc[w];
         }
-        return;
-    }
-    // ---- merge the four waves (fixed order) ----
-    constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes
-    if (lane == 0) wave_ml[wave] = make_float2(run_m, run_l);
+        const float norm = direct ? 1.f / l : 1.f;
+        const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(o, 0, D * (int)sizeof(float), 0x00020000);
+        // element i of the row lives at red[...][i] by construction; D % 4 == 0
+        for (int i = 4 * threadIdx.x; i < D; i += 4 * (WAVES * kWave)) {
+            float r[4];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+            for (int k = 0; k < 4; ++k) {
+                float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) red[wave * kRowF + (j * kWave + lane) * EPL + e] = acc[j][e];
-    __syncthreads();
-    float m = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) m = fmaxf(m, wave_ml[w].x);
-    float wsc[WAVES];
-    float l = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        wsc[w] = wave_ml[w].x == -INFINITY ? 0.f : expf(wave_ml[w].x - m);
-        l += wave_ml[w].y * wsc[w];
-    }
-    float* o = direct ? out + (int64_t)b * D : partial + ((int64_t)b * nchunk_max + c) * D;
-    const float norm = direct ? 1.f / l : 1.f;
-    for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) {  // element i of the row lives at red[...][i] by construction
-        float r = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) r += red[w * kRowF + i] * wsc[w];
-        o[i] = r * norm;
+                for (int w = 0; w < WAVES; ++w) t += red[w * kRowF + i + k] * wsc[w];
+                r[k] = t * norm;
+            }
+            if (publish) {
+                fu_u32x4 raw;
+                raw.x = __float_as_uint(r[0]); raw.y = __float_as_uint(r[1]); raw.z = __float_as_uint(r[2]); raw.w = __float_as_uint(r[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(raw, orow, i * (int)sizeof(float), 0, 16);
+            } else {
+                *reinterpret_cast<float4*>(o + i) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
     }
     if (direct) {
-        // whole row handled by this workgroup: normalise the scores in place and write the zero tail
-        __syncthreads();  // raw scores written by other waves of this workgroup are visible after the barrier
-        const float inv_l = 1.f / l;
-        for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
-    } else if (threadIdx.x == 0) {
-        ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
+        if (SCORES) {
+            // whole row handled by this workgroup: normalise the scores in place and write the zero tail
+            __syncthreads();  // raw scores written by other waves of this workgroup are visible after the barrier
+            const float inv_l = 1.f / l;
+            for (int i = threadIdx.x; i < S; i += (WAVES * kWave)) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
+        }
+    } else if (!publish) {
+        if (threadIdx.x == 0) ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
+    } else {
+        // ---- publish the triple, count the arrival; the workgroup that completes the row merges it ----
+        typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
+        typedef unsigned __attribute__((address_space(1)))* gu32_ptr;
+        int* last_sh = reinterpret_cast<int*>(wave_ml);  // free by now: every read of wave_ml is behind a barrier
+        float2* ml_row = ml + (int64_t)b * ml_per_row;
+        if (threadIdx.x == 0) {
+            const unsigned long long packed = ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m);
+            __hip_atomic_store((gu64_ptr)(ml_row + c), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave: its write-through stores have left
+        __syncthreads();
+        const int nc = row_items(L, ct, tail);            // items of this row that do work, i.e. arrivals to expect
+        if (threadIdx.x == 0) {
+            const unsigned before = __hip_atomic_fetch_add((gu32_ptr)(arrivals + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = before + 1u == (unsigned)nc;
+            if (last) {
+                __hip_atomic_store((gu32_ptr)(arrivals + b), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's L1 copies of the other chunks' lines
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and hold the barrier until that has happened
+            }
+            *last_sh = last;
+        }
+        __syncthreads();
+        if (*last_sh) {
+            // chunk statistics -> LDS (the scan's reduction buffer is free now); sc1 loads: served by L2 / memory, never L1
+            float2* ml_sh = reinterpret_cast<float2*>(red);
+            for (int i = threadIdx.x; i < nc; i += (WAVES * kWave)) {
+                const unsigned long long packed = __hip_atomic_load((gu64_ptr)(ml_row + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ml_sh[i] = make_float2(__uint_as_float((unsigned)packed), __uint_as_float((unsigned)(packed >> 32)));
+            }
+            __syncthreads();
+            float mm = -INFINITY;
+            for (int i = 0; i < nc; ++i) mm = fmaxf(mm, ml_sh[i].x);
+            float ll = 0.f;
+            for (int i = 0; i < nc; ++i) ll = fmaf(ml_sh[i].y, expf(ml_sh[i].x - mm), ll);
+            const float inv_l = 1.f / ll;
+            const float* pr = partial + (int64_t)b * slots * D;
+            for (int d = 4 * threadIdx.x; d < D; d += 4 * (WAVES * kWave)) {
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int i0 = 0; i0 < nc; i0 += 8) {   // up to 8 chunk rows in flight
+                    fu_u32x4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (i0 + k < nc) {
+                            const float* row_i = pr + (int64_t)(i0 + k) * D;
+                            const __amdgpu_buffer_rsrc_t prow =
+                                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row_i), 0, D * (int)sizeof(float), 0x00020000);
+                            v[k] = __builtin_amdgcn_raw_buffer_load_b128(prow, d * (int)sizeof(float), 0, 16);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (i0 + k < nc) {
+                            const float w = expf(ml_sh[i0 + k].x - mm);
+                            r[0] = fmaf(__uint_as_float(v[k].x), w, r[0]);
+                            r[1] = fmaf(__uint_as_float(v[k].y), w, r[1]);
+                            r[2] = fmaf(__uint_as_float(v[k].z), w, r[2]);
+                            r[3] = fmaf(__uint_as_float(v[k].w), w, r[3]);
+                        }
+                    }
+                }
+                *reinterpret_cast<float4*>(out + (int64_t)b * D + d) =
+                    make_float4(r[0] * inv_l, r[1] * inv_l, r[2] * inv_l, r[3] * inv_l);
+            }
+        }
     }
     MLI_TRACE(4);
 #ifdef MLI_SCAN_TRACE
@@ -366,16 +483,16 @@ constexpr int kCombineParts = 4;
 
 __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
     const float2* __restrict__ ml, const float* __restrict__ partial, const int* __restrict__ lengths,
-    float* __restrict__ qkt, float* __restrict__ out, int S, int D, int ct, int ml_per_row, int nchunk_max) {
+    float* __restrict__ qkt, float* __restrict__ out, int S, int D, int ct, int ml_per_row, int slots, int tail) {
     const int b = blockIdx.x;
     const int part = blockIdx.y;
     const int L = min(lengths[b], S);
-    const int nc = (L + ct - 1) / ct;
+    const int nc = row_items(L, ct, tail);
     float* qkt_row = qkt + (int64_t)b * S;
     const int per = ((S + kCombineParts - 1) / kCombineParts + 3) & ~3;
     const int i0 = part * per, i1 = min(S, i0 + per);
     if (nc == 0) {
-        for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = 0.f;
+        if (qkt != nullptr) for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = 0.f;
         if (part == 0) for (int i = threadIdx.x; i < D; i += kFuThreads) out[(int64_t)b * D + i] = 0.f;
         return;
     }
@@ -383,46 +500,62 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
     float m = -INFINITY;
     for (int i = 0; i < nc; ++i) m = fmaxf(m, row[i].x);
     float l = 0.f;
-    for (int i = 0; i < nc; ++i) l += row[i].y * expf(row[i].x - m);
+    for (int i = 0; i < nc; ++i) l = fmaf(row[i].y, expf(row[i].x - m), l);
     const float inv_l = 1.f / l;
     if (part == 0) {
-        const float* pr = partial + (int64_t)b * nchunk_max * D;
+        const float* pr = partial + (int64_t)b * slots * D;
         for (int d = threadIdx.x; d < D; d += kFuThreads) {
             float r = 0.f;
-            for (int i = 0; i < nc; ++i) r += pr[(int64_t)i * D + d] * expf(row[i].x - m);
+            for (int i = 0; i < nc; ++i) r = fmaf(pr[(int64_t)i * D + d], expf(row[i].x - m), r);
             out[(int64_t)b * D + d] = r * inv_l;
         }
     }
+    if (qkt == nullptr) return;  // lean mode: the scores were never written
     for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
 }
 
 static int g_flash = 1;
 static int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
-static int g_partial_last = 1;   // mli_tune "scan_partial_last": full chunks first, each row's partial chunk in a last grid row
+// mli_tune "scan_partial_last": 1 (default) = full chunks first, every row's remainder behind them in pieces of
+// "scan_tail_tokens" tokens; 0 = plain chunk order
+static int g_partial_last = 1;
 void set_partial_last(int v) { g_partial_last = v != 0; }
+// mli_tune "scan_tail_tokens": 0 (default) = 128-token pieces (the whole remainder as one piece when the chunk is not
+// larger than that), else a power of two in [64, chunk]
+static int g_tail_tokens = 0;
+void set_tail_tokens(int v) { g_tail_tokens = v; }
 // mli_tune "scan_dynamic_items": ticketed (row, chunk) assignment.  Off by default: it shortens the kernel by 0.6-1.5 %
 // (4-10 us at config 4), and the hipMemsetAsync that zeroes the counter before every launch costs the stream ~8 us.
 static int g_dynamic_items = 0;
 void set_dynamic_items(int v) { g_dynamic_items = v != 0; }
+// mli_tune "scan_merge" (lean mode only): 1 (default) = the workgroup that completes a row merges its chunks inside
+// the scan launch, 0 = the separate combine launch (bit-identical results)
+static int g_scan_merge = 1;
+void set_scan_merge(int v) { g_scan_merge = v != 0; }
 void set_flash_decode(int v) { g_flash = v != 0; }
 void set_flash_variant(int v) { g_flash_variant = v; }
 
-// Tokens per workgroup of the single-pass scan: the largest power of two <= 512 that still gives two workgroups
-// per CU.  Measured: B=1024, S=4096 -> 512 (256: +2.4 %, 1024: +1 % with ragged lengths); B=256, S=1024 -> 512
-// (scan + combine 49.5 us; 64-token chunks, what the 8192-unit rule of the separate softmax.V kernel picks: 61 us).
+// Tokens per workgroup of the single-pass scan: the largest power of two <= 512 that still cuts the batch into
+// >= 2048 (row, chunk) slots, i.e. with ragged lengths about two rounds of real items for the 512 workgroups the chip
+// holds.  Measured: B=1024, S=4096 -> 512 (256: +2.4 %, 1024: +1 % with ragged lengths); B=256, S=1024 -> 128 (round 2,
+// scan launch: 46.9 us against 49.6 at 256 and 54.3 at 512, where 384 items of very unequal size cannot even fill the
+// 512 slots once; lean form 52.5 / 53.1 / 56.2).
 static int fused_chunk_tokens(int B, int S) {
     if (tuned_chunk_tokens() != 0) return sv_chunk_tokens_for(B, S);  // forced (mli_tune / MLI_CHUNK_TOKENS)
     int ct = 512;
-    while (ct > 64 && (int64_t)B * ceil_div_i(S, ct) < 512) ct >>= 1;
+    while (ct > 64 && (int64_t)B * ceil_div_i(S, ct) < 2048) ct >>= 1;
     return ct;
 }
 
 // returns 1 when the fused path ran, 0 when the caller should take the three-kernel path, < 0 / > 1 on error
-// phases: bit 0 = scan kernel, bit 1 = combine kernel (3 = the whole block; 1 / 2 let bench.py time them apart)
+// phases: bit 0 = scan kernel, bit 1 = combine kernel (3 = the whole block; 1 / 2 let bench.py time them apart),
+//         bit 2 = lean mode: qkt is neither read nor written (may be null), and with "scan_merge" on there is no
+//         combine launch -- the scan merges each row itself (phases 5 then does the whole job, 6 nothing)
 template <class E>
 static int launch_fused_decode(const float* q, const void* const* page_table, const int* lengths, float* qkt,
                                float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st,
                                int phases = 3) {
+    const bool lean = (phases & 4) != 0;
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
     if (!g_flash || nj > 8 || D % E::EPL != 0 || S % kPage != 0) return 0;
@@ -430,7 +563,7 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     const int nj_ds = ceil_div_i(Du, kWave * kFuWaves);  // 1 or 2
     // variant 3: single-wave workgroups of 128 tokens -- every wave is its own scheduling unit, no LDS merge,
     // no barrier; the hardware dispatcher does the load balancing
-    const bool solo = g_flash_variant == 3 && S > 128 && !dsplit;
+    const bool solo = g_flash_variant == 3 && S > 128 && !dsplit && !(phases & 4);
     // short sequences with a full batch: one workgroup per row (no partials, no combine launch) beats two 64-token
     // chunks (README workload, S = 128: 200 vs 209 us)
     const int ct = solo ? 128 : (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : fused_chunk_tokens(B, S);
@@ -445,6 +578,9 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + stats_bytes);
     }
     const int ml_per_row = ceil_div_i(S, 64);
+    // lean mode: arrival counters (one per row, zero between launches) in front of the workspace body
+    unsigned* arrivals = nullptr;
+    if (lean && !direct && g_scan_merge && B <= kMaxArrivalRows) arrivals = ws_arrivals(ws);  // ws != nullptr: checked above
     // ticket counter for the dynamic (row, chunk) assignment: in the part of the workspace the partial sums of this
     // chunk size leave unused, zeroed on the stream before every launch
     unsigned* ticket = nullptr;
@@ -456,17 +592,45 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         }
     }
     const int waves = solo ? 1 : kFuWaves;
-    const size_t smem = (size_t)(ct / kPage) * 8 +
-                        (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
+    // page pointers of the chunk | reduction buffer (also holds the row's chunk statistics during the in-kernel merge)
+    const size_t red_bytes = (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
+    const size_t stat_bytes_row = (size_t)ml_per_row * 8;  // upper bound of the triples a row can have
+    const size_t smem = (size_t)(ct / kPage) * 8 + (red_bytes > stat_bytes_row ? red_bytes : stat_bytes_row);
     dim3 grid(B, nchunk);
-    const int partial_last = (!direct && ticket == nullptr && g_partial_last) ? 1 : 0;
-    if (partial_last) grid = dim3(B, nchunk + 1);
+    // tail > 0: full chunks first, the remainders behind them in pieces of `tail` tokens (slots = triples per row)
+    int tail = 0, slots = nchunk;
+    if (!direct && ticket == nullptr && g_partial_last) {
+        tail = g_tail_tokens ? g_tail_tokens : 128;
+        if (tail > ct || tail < 64 || (tail & (tail - 1))) tail = ct;
+        // (the workspace is sized for 64-token chunks: room for every layout with fewer items per row than that)
+        if (nchunk + ct / tail > ml_per_row) tail = ct;
+        slots = nchunk + ct / tail;
+        grid = dim3(B, slots);
+        if ((size_t)B * slots * D * sizeof(float) + stats_bytes > ws_bytes) return 0;
+    }
     const bool nt = nt_loads_enabled();
 #define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES, ...)                                                              \
     hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
                        dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \
-                       ml_per_row, nchunk, direct, ticket, partial_last)
-    if (phases & 1) {
+                       ml_per_row, nchunk, direct, ticket, tail, slots, arrivals)
+    if ((phases & 1) && lean) {
+        // the default register budget only (the variants are tuning experiments of the materialising form)
+        if (dsplit) {
+            if (nj_ds == 1) {
+                if (nt) MLI_FU_LAUNCH(1, true, 8, 2, 4, true, false);
+                else MLI_FU_LAUNCH(1, false, 8, 2, 4, true, false);
+            } else {
+                if (nt) MLI_FU_LAUNCH(2, true, 4, 2, 4, true, false);
+                else MLI_FU_LAUNCH(2, false, 4, 2, 4, true, false);
+            }
+        } else if (nj == 1) {
+            if (nt) MLI_FU_LAUNCH(1, true, 8, 2, 4, false, false);
+            else MLI_FU_LAUNCH(1, false, 8, 2, 4, false, false);
+        } else {
+            if (nt) MLI_FU_LAUNCH(2, true, 4, 2, 4, false, false);
+            else MLI_FU_LAUNCH(2, false, 4, 2, 4, false, false);
+        }
+    } else if (phases & 1) {
         if (dsplit) {
             if (nj_ds == 1) {
                 if (nt) MLI_FU_LAUNCH(1, true, 8, 2, 4, true);
@@ -490,25 +654,27 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
 #undef MLI_FU_LAUNCH
     int rc = launch_status();
     if (rc) return rc > 0 ? rc + 1 : rc;  // keep 1 free for "ran"
-    if (!direct && (phases & 2)) {
-        hipLaunchKernelGGL(fused_decode_combine_kernel, dim3(B, kCombineParts), dim3(kFuThreads), 0, st, ml, partial,
-                           lengths, qkt, out, S, D, ct, ml_per_row, nchunk);
+    if (!direct && (phases & 2) && arrivals == nullptr) {
+        // lean: one part per row, no score pass (qkt == nullptr)
+        hipLaunchKernelGGL(fused_decode_combine_kernel, dim3(B, lean ? 1 : kCombineParts), dim3(kFuThreads), 0, st, ml,
+                           partial, lengths, lean ? nullptr : qkt, out, S, D, ct, ml_per_row, slots, tail);
         rc = launch_status();
         if (rc) return rc > 0 ? rc + 1 : rc;
     }
     return 1;
 }
 
+// qkt == nullptr selects the lean mode (no scores, in-kernel merge)
 int launch_fused_decode_f32(const float* q, const float* const* page_table, const int* lengths, float* qkt, float* out,
                             int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_fused_decode<ElemF32>(q, reinterpret_cast<const void* const*>(page_table), lengths, qkt, out, B, S, D,
-                                        ws, ws_bytes, st);
+                                        ws, ws_bytes, st, qkt == nullptr ? 7 : 3);
 }
 
 int launch_fused_decode_bf16(const float* q, const uint16_t* const* page_table, const int* lengths, float* qkt,
                              float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_fused_decode<ElemBF16>(q, reinterpret_cast<const void* const*>(page_table), lengths, qkt, out, B, S, D,
-                                         ws, ws_bytes, st);
+                                         ws, ws_bytes, st, qkt == nullptr ? 7 : 3);
 }
 
 }  // namespace mli
@@ -517,7 +683,9 @@ extern "C" int mli_decode_scan_paged(const float* q_output, const void* const* p
                                      float* qkt_output, float* attention_result, int n_batch, int n_sequence,
                                      int emb_dim, int elem_bf16, int phases, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-    if (phases < 1 || phases > 3) return MLI_ERR_BAD_ARG;
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
+    if (phases < 1 || phases > 7 || phases == 4) return MLI_ERR_BAD_ARG;
+    if (!(phases & 4) && qkt_output == nullptr) return MLI_ERR_BAD_ARG;
     hipStream_t st = mli::as_stream(stream);
     const int r = elem_bf16 ? mli::launch_fused_decode<mli::ElemBF16>(q_output, page_table, lengths, qkt_output,
                                                                       attention_result, n_batch, n_sequence, emb_dim,

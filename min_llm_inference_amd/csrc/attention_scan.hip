@@ -23,6 +23,8 @@ constexpr int kMinChunkTokens = 64;
 void set_bf16_native_mfma(int v);  // proj_gemm.hip
 void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
+void set_scan_merge(int v);
+void set_tail_tokens(int v);
 void set_dynamic_items(int v);
 void set_partial_last(int v);
 void set_gemm_tall_tiles(int v);
@@ -458,8 +460,8 @@ int launch_softmax_v_combine(const float* partial, const int* lengths, float* ou
     return launch_status();
 }
 
-// Workspace layout (mli_attention_workspace_bytes): [chunk statistics: B * ceil(S/64) float2, 256-B aligned]
-// [softmax.V partial sums: B * nchunk * D floats].
+// Workspace layout (mli_attention_workspace_bytes): [row arrival counters: kArrivalRegionBytes, device_common.hpp] then the
+// body every launcher here sees: [chunk statistics: B * ceil(S/64) float2, 256-B aligned][partial sums: B * nchunk * D floats].
 static size_t stats_region_bytes(int B, int S) {
     const size_t n = (size_t)B * ceil_div_i(S, kMinChunkTokens) * sizeof(float2);
     return (n + 255) & ~(size_t)255;
@@ -609,6 +611,10 @@ int launch_scores_softmax_v_naive(const float* q, const float* kt, const float* 
 
 // exported to attention_scan_bf16.hip
 size_t stats_region_bytes_for(int B, int S) { return stats_region_bytes(B, S); }
+static size_t partial_region_bytes(int B, int S, int D) {
+    const size_t nchunk = (size_t)ceil_div_i(S, kMinChunkTokens);
+    return nchunk <= 1 ? 0 : (size_t)B * nchunk * (size_t)D * sizeof(float);
+}
 int fused_softmax_wanted(int B, int S) {
     return g_fused_softmax == 1 || (g_fused_softmax < 0 && (int64_t)B * S <= (1 << 20));
 }
@@ -619,10 +625,15 @@ extern "C" {
 
 size_t mli_attention_workspace_bytes(int n_batch, int n_sequence, int dim) {
     if (n_batch <= 0 || n_sequence <= 0 || dim <= 0) return 0;
-    // [chunk statistics][partial sums], sized for the smallest chunk the heuristic (or the tuning knob) may choose
-    const size_t nchunk = (size_t)mli::ceil_div_i(n_sequence, mli::kMinChunkTokens);
-    const size_t partial = nchunk <= 1 ? 0 : (size_t)n_batch * nchunk * (size_t)dim * sizeof(float);
-    return mli::stats_region_bytes(n_batch, n_sequence) + partial;
+    // [row arrival counters, fixed size][chunk statistics][partial sums], the last two sized for the smallest chunk the
+    // heuristic (or the tuning knob) may choose
+    return mli::kArrivalRegionBytes + mli::stats_region_bytes(n_batch, n_sequence) +
+           mli::partial_region_bytes(n_batch, n_sequence, dim);
+}
+
+int mli_attention_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace == nullptr || workspace_bytes < mli::kArrivalRegionBytes) return MLI_ERR_WORKSPACE;
+    return (int)hipMemsetAsync(workspace, 0, mli::kArrivalRegionBytes, mli::as_stream(stream));
 }
 
 int mli_qkt(const float* q_output, const float* kt_cache, const int* lengths, float* qkt_output,
@@ -639,6 +650,7 @@ int mli_softmax_in_place_with_lengths(float* qkt_output, const int* lengths, int
 int mli_softmax_v(const float* softmax_result, const float* v_cache, const int* lengths, float* attention_result,
                   int n_batch, int n_sequence, int output_dim, void* workspace, size_t workspace_bytes,
                   void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     return mli::launch_softmax_v_naive(softmax_result, v_cache, lengths, attention_result, n_batch, n_sequence,
                                        output_dim, workspace, workspace_bytes, mli::as_stream(stream));
 }
@@ -652,6 +664,7 @@ int mli_qkt_paged(const float* q_output, const float* const* page_table, const i
 int mli_softmax_v_paged(const float* softmax_result, const float* const* page_table, const int* lengths,
                         float* attention_result, int n_batch, int n_sequence, int emb_dim, void* workspace,
                         size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     return mli::launch_softmax_v_paged(softmax_result, page_table, lengths, attention_result, n_batch, n_sequence,
                                        emb_dim, workspace, workspace_bytes, mli::as_stream(stream));
 }
@@ -673,8 +686,13 @@ int mli_tune(const char* key, int value) {
         mli::set_gemm_tall_tiles(value);
     } else if (k == "scan_partial_last") {
         mli::set_partial_last(value);
+    } else if (k == "scan_tail_tokens") {
+        if (value != 0 && (value < 64 || value > 1024 || (value & (value - 1)))) return MLI_ERR_BAD_ARG;
+        mli::set_tail_tokens(value);
     } else if (k == "scan_dynamic_items") {
         mli::set_dynamic_items(value);
+    } else if (k == "scan_merge") {
+        mli::set_scan_merge(value);
     } else if (k == "flash_variant") {
         mli::set_flash_variant(value);
     } else if (k == "flash_decode") {

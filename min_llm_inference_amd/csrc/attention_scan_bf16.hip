@@ -344,6 +344,7 @@ int mli_qkt_paged_bf16(const float* q_output, const mli_bf16* const* page_table,
 int mli_softmax_v_paged_bf16(const float* softmax_result, const mli_bf16* const* page_table, const int* lengths,
                              float* attention_result, int n_batch, int n_sequence, int emb_dim, void* workspace,
                              size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     return mli::launch_softmax_v_paged_bf16(softmax_result, page_table, lengths, attention_result, n_batch,
                                             n_sequence, emb_dim, workspace, workspace_bytes, mli::as_stream(stream));
 }

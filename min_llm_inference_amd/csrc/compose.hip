@@ -41,12 +41,83 @@ int launch_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*
 
 extern "C" {
 
-int mli_abi_version(void) { return 2; }
+int mli_abi_version(void) { return 3; }
+
+int mli_paged_attention_lean(void* const* page_table, const int* lengths, const void* wk, const void* wq, const void* wv,
+                             const int* new_batch_idx, float* q_output, float* attention_result, int n_batch,
+                             int n_sequence, int emb_dim, int n_new_items, int elem_bf16, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
+    hipStream_t st = mli::as_stream(stream);
+    int rc, fused;
+    if (elem_bf16) {
+        mli_bf16* const* pt = reinterpret_cast<mli_bf16* const*>(page_table);
+        const mli_bf16 *k = static_cast<const mli_bf16*>(wk), *q = static_cast<const mli_bf16*>(wq), *v = static_cast<const mli_bf16*>(wv);
+        rc = mli::launch_fill_paged_bf16(pt, new_batch_idx, lengths, k, v, n_batch, n_sequence, emb_dim, n_new_items, st);
+        if (!rc) rc = mli::launch_latest_paged_bf16(pt, lengths, k, q, v, q_output, n_batch, n_sequence, emb_dim, st);
+        if (rc) return rc;
+        fused = mli::launch_fused_decode_bf16(q_output, pt, lengths, nullptr, attention_result, n_batch, n_sequence,
+                                              emb_dim, workspace, workspace_bytes, st);
+    } else {
+        float* const* pt = reinterpret_cast<float* const*>(page_table);
+        const float *k = static_cast<const float*>(wk), *q = static_cast<const float*>(wq), *v = static_cast<const float*>(wv);
+        rc = mli::launch_fill_paged(pt, new_batch_idx, lengths, k, v, n_batch, n_sequence, emb_dim, n_new_items, st);
+        if (!rc) rc = mli::launch_latest_paged(pt, lengths, k, q, v, q_output, n_batch, n_sequence, emb_dim, st);
+        if (rc) return rc;
+        fused = mli::launch_fused_decode_f32(q_output, pt, lengths, nullptr, attention_result, n_batch, n_sequence,
+                                             emb_dim, workspace, workspace_bytes, st);
+    }
+    if (fused == 1) return 0;
+    // rows too wide for the single-pass kernel (or no workspace): the caller takes the materialising composition
+    if (fused == 0) return MLI_ERR_BAD_ARG;
+    return fused < 0 ? fused : fused - 1;
+}
+
+int mli_graph_begin_capture(void* stream) {
+    if (stream == nullptr) return MLI_ERR_BAD_ARG;  // the legacy default stream cannot be captured
+    return (int)hipStreamBeginCapture(mli::as_stream(stream), hipStreamCaptureModeThreadLocal);
+}
+
+int mli_graph_end_capture(void* stream, void** graph_exec_out) {
+    if (stream == nullptr || graph_exec_out == nullptr) return MLI_ERR_BAD_ARG;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(mli::as_stream(stream), &graph);
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec_out = exec;
+    return 0;
+}
+
+int mli_stream_wait_stream(void* waiter, void* signaller) {
+    // events are cheap to create and may be destroyed as soon as both calls have been issued: the runtime keeps what it
+    // needs until the work has passed (eager), or has already turned it into a graph edge (capture)
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventRecord(ev, mli::as_stream(signaller));
+    if (e == hipSuccess) e = hipStreamWaitEvent(mli::as_stream(waiter), ev, 0);
+    (void)hipEventDestroy(ev);
+    return (int)e;
+}
+
+int mli_graph_launch(void* graph_exec, void* stream) {
+    if (graph_exec == nullptr) return MLI_ERR_BAD_ARG;
+    return (int)hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), mli::as_stream(stream));
+}
+
+int mli_graph_destroy(void* graph_exec) {
+    if (graph_exec == nullptr) return 0;
+    return (int)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec));
+}
 
 int mli_paged_attention_bf16(mli_bf16* const* page_table, const int* lengths, const mli_bf16* wk, const mli_bf16* wq,
                              const mli_bf16* wv, const int* new_batch_idx, float* q_output, float* qkt_output,
                              float* attention_result, int n_batch, int n_sequence, int emb_dim, int n_new_items,
                              void* workspace, size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     hipStream_t st = mli::as_stream(stream);
     int rc = mli::launch_fill_paged_bf16(page_table, new_batch_idx, lengths, wk, wv, n_batch, n_sequence, emb_dim,
                                          n_new_items, st);
@@ -66,6 +137,7 @@ int mli_inference_self_attention(const float* inp_embedding, const int* lengths,
                                  float* q_output, float* qkt_output, float* attention_result, int n_batch,
                                  int n_sequence, int input_dim, int output_dim, int n_new_items, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     hipStream_t st = mli::as_stream(stream);
     int rc = mli::launch_fill_naive(inp_embedding, new_batch_idx, lengths, wk, wv, kt_cache, v_cache, n_batch,
                                     n_sequence, input_dim, output_dim, n_new_items, st);
@@ -81,6 +153,7 @@ int mli_paged_attention(float* const* page_table, const int* lengths, const floa
                         const float* wv, const int* new_batch_idx, float* q_output, float* qkt_output,
                         float* attention_result, int n_batch, int n_sequence, int emb_dim, int n_new_items,
                         void* workspace, size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     hipStream_t st = mli::as_stream(stream);
     int rc = mli::launch_fill_paged(page_table, new_batch_idx, lengths, wk, wv, n_batch, n_sequence, emb_dim,
                                     n_new_items, st);

@@ -155,6 +155,24 @@ __device__ __forceinline__ void stats_merge_row(const SoftmaxStats& st, int b, i
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Caller-owned workspace = [row arrival counters of the lean single-pass scan][body: chunk statistics | partial sums].
+// The counters sit at a FIXED place in front: calls of different shapes share one buffer, and a place that moved with
+// the shape would sooner or later hold another call's partial sums -- the counters must stay zero between launches.
+// Every extern "C" entry point converts (workspace, bytes) to the body once; the kernels' launchers see only the body.
+constexpr size_t kArrivalRegionBytes = 65536;                        // 16384 rows
+constexpr int kMaxArrivalRows = (int)(kArrivalRegionBytes / sizeof(unsigned));
+struct WsBody {
+    void* ptr;
+    size_t bytes;
+};
+inline WsBody ws_body(void* workspace, size_t bytes) {
+    if (workspace == nullptr || bytes <= kArrivalRegionBytes) return WsBody{nullptr, 0};
+    return WsBody{reinterpret_cast<char*>(workspace) + kArrivalRegionBytes, bytes - kArrivalRegionBytes};
+}
+inline unsigned* ws_arrivals(void* body) {
+    return body == nullptr ? nullptr : reinterpret_cast<unsigned*>(reinterpret_cast<char*>(body) - kArrivalRegionBytes);
+}
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

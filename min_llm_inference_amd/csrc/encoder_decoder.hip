@@ -5,11 +5,13 @@
 //   src/kernels/utils.cu:106-160   (clone_inp_embedding_k_v_cache)
 #include <cfloat>
 
-#include "device_common.hpp"
+#include "gemm_common.hpp"
 
 namespace mli {
 
 int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int K, hipStream_t st);
+int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, hipStream_t st);
+int gemm_nt_argmax_tiles(int N);
 
 constexpr int kEdThreads = 256;
 
@@ -119,6 +121,55 @@ __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     for (int i = threadIdx.x; i < (D >> 2); i += kEdThreads) store_sum4<BF16>(dst, i, e[i], p[i]);
 }
 
+// The decoder head behind the logits GEMM's argmax epilogue (proj_gemm.hip: launch_gemm_nt_argmax): one WAVE per batch
+// row picks the row's best (value, index) pair among the column tiles' pairs -- larger value, then lower index, the
+// order decoder_argmax_kernel applies to the scores themselves, so the token is the same -- then updates the length
+// and writes the next input embedding exactly as decoder_argmax_kernel does (reference decoder.cu:128-205).
+constexpr int kFinalizeRows = kEdThreads / kWave;  // batch rows per workgroup
+
+template <bool PAGED, bool BF16 = false>
+__global__ __launch_bounds__(kEdThreads) void decoder_finalize_kernel(
+    const RowBest* __restrict__ row_best, int n_tiles, int* __restrict__ decoder_result, int* __restrict__ lengths,
+    float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const float* __restrict__ wpe_table,
+    const float* __restrict__ emb_table, int B, int S, int D, int n_decoder_results, int i_decoder) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int b = blockIdx.x * kFinalizeRows + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int L = lengths[b];
+    if (L == 0) {  // empty slot
+        if (lane == 0) decoder_result[(int64_t)b * n_decoder_results + i_decoder] = MLI_EMPTY_ROW_TOKEN_ID;
+        return;
+    }
+    float mv = -FLT_MAX;
+    int mi = -1;
+    for (int t = lane; t < n_tiles; t += kWave) {
+        const RowBest rb = row_best[(int64_t)b * n_tiles + t];
+        argmax_take(mv, mi, rb.value, rb.index);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(mv, off, kWave);
+        const int oi = __shfl_xor(mi, off, kWave);
+        argmax_take(mv, mi, ov, oi);
+    }
+    const int tok = mi;  // every lane holds the same pair now
+    const bool done = (L + 1 >= S) || tok == MLI_EOF_TOKEN_ID;
+    float* page = nullptr;
+    if (PAGED && !done) page = page_table[(int64_t)b * (S / kPage) + L / kPage];  // same address in every lane: one request
+    if (lane == 0) {
+        decoder_result[(int64_t)b * n_decoder_results + i_decoder] = tok;
+        lengths[b] = done ? 0 : L + 1;
+    }
+    if (done || tok < 0) return;               // finished rows get no next embedding
+    if (PAGED && page == nullptr) return;      // no page for the next position (a caller bug): skip rather than fault
+    const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
+    const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
+    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D
+                 : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page) + page_row_offset(L, D, kSegInp))
+                        : page + page_row_offset(L, D, kSegInp);
+    for (int i = lane; i < (D >> 2); i += kWave) store_sum4<BF16>(dst, i, e[i], p[i]);
+}
+
 // grid = (S/16, B).  Positions 0..min(L, S-1) inclusive are cloned (the decoder writes the next
 // position's embedding, so one more than the length is materialised; reference utils.cu:125-127).
 __global__ __launch_bounds__(kEdThreads) void clone_to_pages_kernel(
@@ -225,6 +276,57 @@ int mli_paged_decoder_multi_rounds(const float* batch_result, const float* emb_t
                        decoder_result, lengths, (float*)nullptr, page_table, wpe_table, emb_table, n_vocab,
                        n_sequence, emb_dim, n_decoder_results, i_decoder);
     return mli::launch_status();
+}
+
+size_t mli_decoder_scratch_bytes(int n_batch, int n_vocab) {
+    if (n_batch <= 0 || n_vocab <= 0) return 0;
+    return (size_t)n_batch * mli::gemm_nt_argmax_tiles(n_vocab) * sizeof(mli::RowBest);
+}
+
+// layout: 0 = contiguous (inp_embedding), 1 = paged fp32, 2 = paged bf16
+static int decoder_fused(int layout, const float* batch_result, const float* emb_table, const float* wpe_table,
+                         float* inp_embedding, float* const* page_table, int* lengths, int* decoder_result, int n_batch,
+                         int n_vocab, int n_sequence, int emb_dim, int n_decoder_results, int i_decoder, void* scratch,
+                         size_t scratch_bytes, void* stream) {
+    if (emb_dim % (layout == 2 ? 8 : 4) != 0 || n_batch <= 0 || n_vocab <= 0 || n_decoder_results <= 0 || i_decoder < 0 ||
+        i_decoder >= n_decoder_results || (layout != 0 && n_sequence % mli::kPage != 0))
+        return MLI_ERR_BAD_ARG;
+    if (scratch == nullptr || scratch_bytes < mli_decoder_scratch_bytes(n_batch, n_vocab)) return MLI_ERR_WORKSPACE;
+    hipStream_t st = mli::as_stream(stream);
+    mli::RowBest* best = reinterpret_cast<mli::RowBest*>(scratch);
+    int rc = mli::launch_gemm_nt_argmax(batch_result, emb_table, best, n_batch, n_vocab, emb_dim, st);
+    if (rc) return rc;
+    const int n_tiles = mli::gemm_nt_argmax_tiles(n_vocab);
+    const dim3 grid(mli::ceil_div_i(n_batch, mli::kFinalizeRows)), block(mli::kEdThreads);
+    if (layout == 0)
+        hipLaunchKernelGGL((mli::decoder_finalize_kernel<false>), grid, block, 0, st, best, n_tiles, decoder_result, lengths,
+                           inp_embedding, (float* const*)nullptr, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
+                           n_decoder_results, i_decoder);
+    else if (layout == 1)
+        hipLaunchKernelGGL((mli::decoder_finalize_kernel<true>), grid, block, 0, st, best, n_tiles, decoder_result, lengths,
+                           (float*)nullptr, page_table, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
+                           n_decoder_results, i_decoder);
+    else
+        hipLaunchKernelGGL((mli::decoder_finalize_kernel<true, true>), grid, block, 0, st, best, n_tiles, decoder_result,
+                           lengths, (float*)nullptr, page_table, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
+                           n_decoder_results, i_decoder);
+    return mli::launch_status();
+}
+
+int mli_decoder_fused(const float* batch_result, const float* emb_table, const float* wpe_table, float* inp_embedding,
+                      int* lengths, int* decoder_result, int n_batch, int n_vocab, int n_sequence, int emb_dim,
+                      void* scratch, size_t scratch_bytes, void* stream) {
+    return decoder_fused(0, batch_result, emb_table, wpe_table, inp_embedding, nullptr, lengths, decoder_result, n_batch,
+                         n_vocab, n_sequence, emb_dim, 1, 0, scratch, scratch_bytes, stream);
+}
+
+int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, const float* wpe_table,
+                            void* const* page_table, int* lengths, int* decoder_result, int n_batch, int n_vocab,
+                            int n_sequence, int emb_dim, int n_decoder_results, int i_decoder, int elem_bf16, void* scratch,
+                            size_t scratch_bytes, void* stream) {
+    return decoder_fused(elem_bf16 ? 2 : 1, batch_result, emb_table, wpe_table, nullptr,
+                         reinterpret_cast<float* const*>(page_table), lengths, decoder_result, n_batch, n_vocab,
+                         n_sequence, emb_dim, n_decoder_results, i_decoder, scratch, scratch_bytes, stream);
 }
 
 int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp_embedding, const float* kt_cache,

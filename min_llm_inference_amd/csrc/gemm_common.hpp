@@ -37,7 +37,24 @@ struct GemmArgs {
     int n_new;       // fill: number of live entries of new_batch_idx
     int compact;     // 1 = the M dimension is a flat list built on the device (see FillIndex): all (new row, token)
                      // pairs for the fill modes, the non-empty batch rows for the latest modes
+    // kPlain only: when set, C is NOT stored; every workgroup reduces its tile to one (max, lowest index of the max)
+    // pair per row and writes it to row_best[m * tiles_n + tile] -- the decoder's argmax as the logits GEMM's epilogue
+    struct RowBest* row_best;
 };
+
+struct RowBest {
+    float value;
+    int index;
+};
+
+// argmax order: larger value wins, equal values -> the lower index (the reference's host decoder,
+// tests/test_utils.cpp:607-614); index -1 = "nothing yet" compares as the highest index
+__device__ __forceinline__ void argmax_take(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && (unsigned)oi < (unsigned)i)) {
+        v = ov;
+        i = oi;
+    }
+}
 
 // Prefill over a FLAT row list.  A new row's prompt rarely fills a 64-row tile (the reference's workload: prompts of
 // 1..64 tokens), so a grid of (row, tile-of-the-row) workgroups multiplies mostly padding.  Instead every

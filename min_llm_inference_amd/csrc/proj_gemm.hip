@@ -36,6 +36,24 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // KQ: 32-deep k slabs staged per tile.  Only KQ = 1 is instantiated: 128 k per barrier pair (KQ = 4) was measured
 // SLOWER for the latency-bound fp32 shapes (config 4 logits 23.8 -> 26.0 us, D = 2048 logits 61.8 -> 70.2 us) --
 // unlike the bf16 kernel, whose deep tile is a win (proj_gemm_bf16.hip).
+// One step of the argmax butterfly: of its 2 * H candidate rows a lane keeps H (the upper ones when `upper`) and
+// merges into them what its partner (lane ^ mask) held for the same rows.
+template <int H>
+__device__ __forceinline__ void argmax_butterfly_step(float (&v)[16], int (&ix)[16], bool upper, int mask) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const float send_v = upper ? v[k] : v[k + H];
+        const int send_i = upper ? ix[k] : ix[k + H];
+        float keep_v = upper ? v[k + H] : v[k];
+        int keep_i = upper ? ix[k + H] : ix[k];
+        const float ov = __shfl_xor(send_v, mask, kWave);
+        const int oi = __shfl_xor(send_i, mask, kWave);
+        const bool take = ov > keep_v || (ov == keep_v && (unsigned)oi < (unsigned)keep_i);
+        v[k] = take ? ov : keep_v;
+        ix[k] = take ? oi : keep_i;
+    }
+}
+
 template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, int KQ = 1>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup
@@ -233,6 +251,52 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
 
     // epilogue: accumulator register r of lane l is tile element
     //   (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
+    if (MODE == kPlain && g.row_best != nullptr) {
+        // argmax epilogue (decoder logits): a row of the wave's 32x32 sub-tile lies across 32 lanes of one register
+        // -> butterfly over the 5 low lane bits; the two waves that share the rows meet in LDS (the staging tiles are
+        // free after the k loop's last barrier); one (max, index) pair per (row, column tile) goes to memory
+        float* best_v = As;                                   // [BM][2]
+        int* best_i = reinterpret_cast<int*>(As + BM * 2);    // [BM][2]   (BK * LDA >= 4 * BM floats)
+        const int n = n0 + wn + li;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            // a score takes part only if it beats -FLT_MAX, as in decoder_argmax_kernel (NaN and -inf never win)
+            float v[16];
+            int ix[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool takes_part = n < g.N && acc[mt][r] > -3.402823466e+38f;
+                v[r] = takes_part ? acc[mt][r] : -3.402823466e+38f;
+                ix[r] = takes_part ? n : -1;
+            }
+            // Transposing butterfly over the 32 lanes that hold one row per register: at every step a lane keeps half
+            // of its rows and trades the other half with its partner (15 exchanges instead of 16 x 5), branch-free,
+            // so the exchanges of different rows overlap.  Afterwards lane li holds row register (li >> 1) & 15.
+            argmax_butterfly_step<8>(v, ix, (lane & 16) != 0, 16);
+            argmax_butterfly_step<4>(v, ix, (lane & 8) != 0, 8);
+            argmax_butterfly_step<2>(v, ix, (lane & 4) != 0, 4);
+            argmax_butterfly_step<1>(v, ix, (lane & 2) != 0, 2);
+            {
+                const float ov = __shfl_xor(v[0], 1, kWave);
+                const int oi = __shfl_xor(ix[0], 1, kWave);
+                argmax_take(v[0], ix[0], ov, oi);
+            }
+            if ((li & 1) == 0) {
+                const int r = (li >> 1) & 15;
+                const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                best_v[row * 2 + (wave & 1)] = v[0];
+                best_i[row * 2 + (wave & 1)] = ix[0];
+            }
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float v = best_v[tid * 2];
+            int i = best_i[tid * 2];
+            argmax_take(v, i, best_v[tid * 2 + 1], best_i[tid * 2 + 1]);
+            g.row_best[(int64_t)(m0 + tid) * tiles_n + blockIdx.x % tiles_n] = RowBest{v, i};
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -402,6 +466,20 @@ int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int 
     g.w[0] = Bt; g.n_out = 1; g.out_id[0] = 1;
     g.M = M; g.N = N; g.K = K;
     g.a_plain = A; g.c_plain = C; g.lda = K; g.ldc = N;
+    const bool vec4 = K % 4 == 0 && aligned16(A) && aligned16(Bt);
+    return launch_gemm<kPlain, true>(g, M, 1, vec4, st);
+}
+
+// The same product with the argmax epilogue: nothing of C[M, N] is stored, row_best[m][t] = (max, lowest index of the
+// max) over the columns of tile t.  Tiles per row: gemm_nt_argmax_tiles(N).
+int gemm_nt_argmax_tiles(int N) { return ceil_div_i(N, BN); }
+int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, hipStream_t st) {
+    if (M <= 0 || row_best == nullptr) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = Bt; g.n_out = 1; g.out_id[0] = 1;
+    g.M = M; g.N = N; g.K = K;
+    g.a_plain = A; g.c_plain = nullptr; g.lda = K; g.ldc = N;
+    g.row_best = row_best;
     const bool vec4 = K % 4 == 0 && aligned16(A) && aligned16(Bt);
     return launch_gemm<kPlain, true>(g, M, 1, vec4, st);
 }

@@ -28,6 +28,14 @@ void launch_qkt_paged_attention(const TensorFloat& q_output, const TensorFloatPo
 void launch_softmax_v_paged_attention(const TensorFloat& softmax_result, const TensorFloatPoint& page_table,
                                       TensorFloat& attention_result, const TensorInt& lengths);
 
+// EXTENSION (no reference counterpart): paged_attention without materialising scores / probabilities -- q_output and
+// attention_result come out bit-identical, qkt_output is left alone (it is only used when emb_dim exceeds what the
+// single-pass kernel covers).  What PagedAttention[Cublas]Layer::forward runs unless runtime::set_lean_layers(false).
+void paged_attention_lean(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,
+                          const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
+                          TensorFloat& q_output, TensorFloat& qkt_output, TensorFloat& attention_result,
+                          int n_new_items, int n_sequence);
+
 // "cuBLAS" variants: same results, produced by the same gather-GEMM-scatter MFMA kernel.  latest_emb and
 // temp_placeholder were scratch for the three cublasSgemm calls and are accepted but not used.
 void paged_attention_with_cublas(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,

@@ -26,6 +26,13 @@ struct Scratch {
 Scratch attention_scratch(int n_batch, int n_sequence, int emb_dim);
 void release_attention_scratch(void* stream) noexcept;  // frees the buffers tied to a stream that is going away
 
+// What the layers run (process-wide; default true): the LEAN compositions -- attention without materialising scores /
+// probabilities in the layer's qkt_output scratch, decoder head with the argmax as the logits GEMM's epilogue instead of
+// materialising emb_score.  Outputs a caller of forward() can observe (attention_result, tokens, lengths, pages) are
+// bit-identical either way; false reproduces the reference's launch sequence, scratch contents included.
+void set_lean_layers(bool enabled);
+bool lean_layers();
+
 // roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
 void range_push(const char* name);
 void range_pop();

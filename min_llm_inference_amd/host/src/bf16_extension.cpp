@@ -73,8 +73,22 @@ PagedAttentionBf16Layer::PagedAttentionBf16Layer(TensorBf16&& wk, TensorBf16&& w
 void PagedAttentionBf16Layer::forward(TensorFloatPoint& page_table, const TensorInt& lengths,
                                       const TensorInt& new_batch_idx, TensorFloat& attention_result,
                                       int n_new_items) {
+    const int n_sequence = static_cast<int>(qkt_output_.shape()[1]);
+    if (mli::runtime::lean_layers()) {
+        const int B = (int)page_table.shape()[0], D = (int)wk_.shape()[0];
+        const mli::runtime::Scratch ws = mli::runtime::attention_scratch(B, n_sequence, D);
+        const int rc = mli_paged_attention_lean(reinterpret_cast<void* const*>(page_table.data()), lengths.data(),
+                                                wk_.data(), wq_.data(), wv_.data(), new_batch_idx.data(),
+                                                q_output_.data(), attention_result.data(), B, n_sequence, D,
+                                                n_new_items, /*elem_bf16=*/1, ws.ptr, ws.bytes,
+                                                mli::runtime::compute_stream());
+        if (rc != MLI_ERR_BAD_ARG || D <= 4096) {  // rows wider than the single-pass kernel covers: fall through
+            HIP_CHECK(rc);
+            return;
+        }
+    }
     paged_attention_bf16(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_, attention_result,
-                         n_new_items, static_cast<int>(qkt_output_.shape()[1]));
+                         n_new_items, n_sequence);
 }
 
 PagedAttentionBf16InferenceModel::PagedAttentionBf16InferenceModel(PagedAttentionBf16Layer&& attention_layer,
@@ -94,7 +108,16 @@ void PagedAttentionBf16InferenceModel::forward(const TensorInt& inp, TensorInt& 
                                                    page_table.data(), lengths.data(), new_item_indices.data(),
                                                    (int)n_batch_, (int)n_sequence_, (int)emb_dim_, fresh);
         attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
-        launch_paged_attention_decoder_multi_rounds_bf16(attention_result_, emb_table, emb_score_, pos_emb_table,
-                                                         page_table, lengths, decoder_result, round);
+        if (mli::runtime::lean_layers()) {
+            HIP_CHECK(mli_paged_decoder_fused(attention_result_.data(), emb_table.data(), pos_emb_table.data(),
+                                              reinterpret_cast<void* const*>(page_table.data()), lengths.data(),
+                                              decoder_result.data(), (int)n_batch_, (int)emb_table.shape()[0],
+                                              (int)n_sequence_, (int)emb_dim_, n_forward_rounds_, round, /*elem_bf16=*/1,
+                                              emb_score_.data(), emb_score_.get_total_size() * sizeof(float),
+                                              mli::runtime::compute_stream()));
+        } else {
+            launch_paged_attention_decoder_multi_rounds_bf16(attention_result_, emb_table, emb_score_, pos_emb_table,
+                                                             page_table, lengths, decoder_result, round);
+        }
     }
 }

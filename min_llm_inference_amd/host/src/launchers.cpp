@@ -36,11 +36,20 @@ mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequenc
     if (need == 0) return {nullptr, 0};
     std::lock_guard<std::mutex> lock(mu);
     auto& slot = per_device[{mli::runtime::current_device(), mli::runtime::compute_stream()}];
-    if (!slot || slot->get_total_size() < need)
+    if (!slot || slot->get_total_size() < need) {
         slot = std::make_unique<Tensor<char>>(std::vector<size_t>{need}, DeviceType::DEVICE,
                                               TensorDataType::SYNC_ALLOCATE);
+        // the row arrival counters at the front start at zero (once per allocation; the kernels keep them there)
+        HIP_CHECK(mli_attention_workspace_init(slot->data(), need, mli::runtime::compute_stream()));
+    }
     return {slot->data(), need};
 }
+
+namespace {
+bool g_lean_layers = true;
+}
+void mli::runtime::set_lean_layers(bool enabled) { g_lean_layers = enabled; }
+bool mli::runtime::lean_layers() { return g_lean_layers; }
 
 namespace {
 
@@ -166,6 +175,26 @@ void paged_attention(TensorFloatPoint& page_table, const TensorInt& lengths, con
                                   B, n_sequence, D, n_new_items, ws.ptr, ws.bytes, stream()));
 }
 
+// EXTENSION: the composition without the scores (include/mli_kernels.h: mli_paged_attention_lean).  Rows too wide for
+// the single-pass kernel take the materialising composition into the caller's qkt_output scratch instead.
+void paged_attention_lean(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,
+                          const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
+                          TensorFloat& q_output, TensorFloat& qkt_output, TensorFloat& attention_result,
+                          int n_new_items, int n_sequence) {
+    const int B = (int)page_table.shape()[0], D = (int)wk.shape()[0];
+    const Scratch ws = scratch_for(B, n_sequence, D);
+    const int rc = mli_paged_attention_lean(reinterpret_cast<void* const*>(pages(page_table)), lengths.data(), wk.data(),
+                                            wq.data(), wv.data(), new_batch_idx.data(), q_output.data(),
+                                            attention_result.data(), B, n_sequence, D, n_new_items, /*elem_bf16=*/0,
+                                            ws.ptr, ws.bytes, stream());
+    if (rc == MLI_ERR_BAD_ARG && D > 2048 && D % 4 == 0) {
+        paged_attention(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qkt_output, attention_result,
+                        n_new_items, n_sequence);
+        return;
+    }
+    HIP_CHECK(rc);
+}
+
 void paged_attention_with_cublas(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,
                                  const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
                                  TensorFloat& q_output, TensorFloat& qkt_output, TensorFloat& attention_result,
@@ -210,6 +239,31 @@ void launch_paged_attention_decoder_multi_rounds(const TensorFloat& batch_result
                                              decoder_result.data(), (int)batch_result.shape()[0],
                                              (int)emb_table.shape()[0], (int)wpe_table.shape()[0],
                                              (int)batch_result.shape()[1], n_results, i_decoder, stream()));
+}
+
+// EXTENSION: decoder head with the argmax as the logits GEMM's epilogue (mli_decoder_fused /
+// mli_paged_decoder_fused).  emb_score is only lent as scratch: [n_batch, n_vocab] floats hold the
+// [n_batch, ceil(n_vocab / 64)] (value, index) pairs with room to spare; its contents are unspecified afterwards.
+void launch_decoder_fused(const TensorFloat& batch_result, const TensorFloat& emb_table, TensorFloat& emb_score,
+                          const TensorFloat& wpe_table, TensorFloat& inp_embedding, TensorInt& lengths,
+                          TensorInt& decoder_result) {
+    HIP_CHECK(mli_decoder_fused(batch_result.data(), emb_table.data(), wpe_table.data(), inp_embedding.data(),
+                                lengths.data(), decoder_result.data(), (int)batch_result.shape()[0],
+                                (int)emb_table.shape()[0], (int)wpe_table.shape()[0], (int)batch_result.shape()[1],
+                                emb_score.data(), emb_score.get_total_size() * sizeof(float), stream()));
+}
+
+void launch_paged_attention_decoder_fused(const TensorFloat& batch_result, const TensorFloat& emb_table,
+                                          TensorFloat& emb_score, const TensorFloat& wpe_table,
+                                          TensorFloatPoint& page_table, TensorInt& lengths, TensorInt& decoder_result,
+                                          int i_decoder) {
+    const int n_results = decoder_result.shape().size() == 2 ? (int)decoder_result.shape()[1] : 1;
+    HIP_CHECK(mli_paged_decoder_fused(batch_result.data(), emb_table.data(), wpe_table.data(),
+                                      reinterpret_cast<void* const*>(pages(page_table)), lengths.data(),
+                                      decoder_result.data(), (int)batch_result.shape()[0], (int)emb_table.shape()[0],
+                                      (int)wpe_table.shape()[0], (int)batch_result.shape()[1], n_results, i_decoder,
+                                      /*elem_bf16=*/0, emb_score.data(), emb_score.get_total_size() * sizeof(float),
+                                      stream()));
 }
 
 void launch_paged_attention_cublas_decoder_multi_rounds(const TensorFloat& batch_result,

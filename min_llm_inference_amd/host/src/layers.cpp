@@ -6,6 +6,7 @@
 #include "kernels/encoder.h"
 #include "kernels/paged_attention.h"
 #include "kernels/self_attention_inference_optimized.h"
+#include "runtime.h"
 
 namespace {
 TensorFloat device_tensor(std::initializer_list<size_t> shape) {
@@ -36,8 +37,12 @@ PagedAttentionLayer::PagedAttentionLayer(TensorFloat&& wk, TensorFloat&& wq, Ten
 void PagedAttentionLayer::forward(TensorFloatPoint& page_table, const TensorInt& lengths,
                                   const TensorInt& new_batch_idx, TensorFloat& attention_result, int n_new_items) {
     const int n_sequence = static_cast<int>(qkt_output_.shape()[1]);
-    paged_attention(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_, attention_result,
-                    n_new_items, n_sequence);
+    if (mli::runtime::lean_layers())
+        paged_attention_lean(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_,
+                             attention_result, n_new_items, n_sequence);
+    else
+        paged_attention(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_, attention_result,
+                        n_new_items, n_sequence);
 }
 
 PagedAttentionCublasLayer::PagedAttentionCublasLayer(TensorFloat&& wk, TensorFloat&& wq, TensorFloat&& wv,
@@ -52,8 +57,12 @@ void PagedAttentionCublasLayer::forward(TensorFloatPoint& page_table, const Tens
                                         const TensorInt& new_batch_idx, TensorFloat& attention_result,
                                         int n_new_items, GemmHandle& handle) {
     const int n_sequence = static_cast<int>(qkt_output_.shape()[1]);
-    paged_attention_with_cublas(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_,
-                                attention_result, latest_emb_, temp_placeholder_, n_new_items, n_sequence, handle);
+    if (mli::runtime::lean_layers())
+        paged_attention_lean(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_,
+                             attention_result, n_new_items, n_sequence);
+    else
+        paged_attention_with_cublas(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_,
+                                    attention_result, latest_emb_, temp_placeholder_, n_new_items, n_sequence, handle);
 }
 
 void EncoderLayer::forward(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
@@ -79,7 +88,10 @@ DecoderLayer::DecoderLayer(size_t n_batch, size_t n_vocab) : emb_score_(device_t
 void DecoderLayer::forward(const TensorFloat& batch_result, const TensorFloat& emb_table,
                            const TensorFloat& wpe_table, TensorFloat& inp_embedding, TensorInt& lengths,
                            TensorInt& decoder_result) {
-    launch_decoder(batch_result, emb_table, emb_score_, wpe_table, inp_embedding, lengths, decoder_result);
+    if (mli::runtime::lean_layers())
+        launch_decoder_fused(batch_result, emb_table, emb_score_, wpe_table, inp_embedding, lengths, decoder_result);
+    else
+        launch_decoder(batch_result, emb_table, emb_score_, wpe_table, inp_embedding, lengths, decoder_result);
 }
 
 PagedDecoderLayer::PagedDecoderLayer(size_t n_batch, size_t n_vocab)
@@ -88,8 +100,12 @@ PagedDecoderLayer::PagedDecoderLayer(size_t n_batch, size_t n_vocab)
 void PagedDecoderLayer::forward(const TensorFloat& batch_result, const TensorFloat& emb_table,
                                 const TensorFloat& wpe_table, TensorFloatPoint& page_table, TensorInt& lengths,
                                 TensorInt& decoder_result, int i_decoder_round) {
-    launch_paged_attention_decoder_multi_rounds(batch_result, emb_table, emb_score_, wpe_table, page_table, lengths,
-                                                decoder_result, i_decoder_round);
+    if (mli::runtime::lean_layers())
+        launch_paged_attention_decoder_fused(batch_result, emb_table, emb_score_, wpe_table, page_table, lengths,
+                                             decoder_result, i_decoder_round);
+    else
+        launch_paged_attention_decoder_multi_rounds(batch_result, emb_table, emb_score_, wpe_table, page_table,
+                                                    lengths, decoder_result, i_decoder_round);
 }
 
 PagedCublasDecoderLayer::PagedCublasDecoderLayer(size_t n_batch, size_t n_vocab)
@@ -99,6 +115,10 @@ void PagedCublasDecoderLayer::forward(const TensorFloat& batch_result, const Ten
                                       const TensorFloat& wpe_table, TensorFloatPoint& page_table,
                                       TensorInt& lengths, TensorInt& decoder_result, int i_decoder_round,
                                       GemmHandle& handle) {
-    launch_paged_attention_cublas_decoder_multi_rounds(batch_result, emb_table, emb_score_, wpe_table, page_table,
-                                                       lengths, decoder_result, i_decoder_round, handle);
+    if (mli::runtime::lean_layers())
+        launch_paged_attention_decoder_fused(batch_result, emb_table, emb_score_, wpe_table, page_table, lengths,
+                                             decoder_result, i_decoder_round);
+    else
+        launch_paged_attention_cublas_decoder_multi_rounds(batch_result, emb_table, emb_score_, wpe_table, page_table,
+                                                           lengths, decoder_result, i_decoder_round, handle);
 }

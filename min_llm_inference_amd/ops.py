@@ -208,14 +208,100 @@ def launch_paged_attention_decoder_multi_rounds_bf16(batch_result, emb_table, em
            "mli_paged_decoder_multi_rounds_bf16")
 
 
-def decode_scan_paged(q_output, page_table, lengths, qkt_output, attention_result, elem_bf16, phases=3):
-    """Single-pass scores + masked softmax + softmax.V over the pages (mli_decode_scan_paged)."""
+def decode_scan_paged(q_output, page_table, lengths, qkt_output, attention_result, elem_bf16, phases=3, n_sequence=None):
+    """Single-pass scores + masked softmax + softmax.V over the pages (mli_decode_scan_paged).  phases & 4 = lean mode:
+    qkt_output may be None (pass n_sequence then)."""
     B, D = q_output.shape
-    S = qkt_output.shape[1]
+    S = qkt_output.shape[1] if qkt_output is not None else n_sequence
     ws, need = workspace_for(B, S, D, q_output.device)
     _check(load_library().mli_decode_scan_paged(_p(q_output), _p(page_table), _p(lengths), _p(qkt_output),
                                                 _p(attention_result), B, S, D, int(elem_bf16), int(phases), _p(ws),
                                                 need, _stream()), "mli_decode_scan_paged")
+
+
+def paged_attention_lean(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, attention_result, n_new_items,
+                         n_sequence):
+    """What the attention layers run: the paged composition without materialising scores / probabilities
+    (mli_paged_attention_lean); page / weight element type from the weights' dtype."""
+    B = page_table.shape[0]
+    D = wk.shape[0]
+    ws, need = workspace_for(B, n_sequence, D, q_output.device)
+    _check(load_library().mli_paged_attention_lean(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv),
+                                                   _p(new_batch_idx), _p(q_output), _p(attention_result), B, n_sequence,
+                                                   D, n_new_items, int(wk.dtype == torch.bfloat16), _p(ws), need,
+                                                   _stream()), "mli_paged_attention_lean")
+
+
+_decoder_scratch = {}
+
+
+def decoder_scratch_for(n_batch, n_vocab, device):
+    lib = load_library()
+    need = int(lib.mli_decoder_scratch_bytes(n_batch, n_vocab))
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
+    buf = _decoder_scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(max(need, 16), dtype=torch.uint8, device=device)
+        _decoder_scratch[key] = buf
+    return buf, need
+
+
+def decoder_fused(batch_result, emb_table, wpe_table, inp_embedding, lengths, decoder_result):
+    """launch_decoder with the argmax as the logits GEMM's epilogue (no emb_score)."""
+    B, D = batch_result.shape
+    sc, need = decoder_scratch_for(B, emb_table.shape[0], batch_result.device)
+    _check(load_library().mli_decoder_fused(_p(batch_result), _p(emb_table), _p(wpe_table), _p(inp_embedding),
+                                            _p(lengths), _p(decoder_result), B, emb_table.shape[0], wpe_table.shape[0],
+                                            D, _p(sc), need, _stream()), "mli_decoder_fused")
+
+
+def paged_decoder_fused(batch_result, emb_table, wpe_table, page_table, lengths, decoder_result, i_decoder, elem_bf16):
+    """launch_paged_attention[_cublas]_decoder_multi_rounds with the argmax as the logits GEMM's epilogue."""
+    B, D = batch_result.shape
+    n_res = decoder_result.shape[1] if decoder_result.dim() == 2 else 1
+    sc, need = decoder_scratch_for(B, emb_table.shape[0], batch_result.device)
+    _check(load_library().mli_paged_decoder_fused(_p(batch_result), _p(emb_table), _p(wpe_table), _p(page_table),
+                                                  _p(lengths), _p(decoder_result), B, emb_table.shape[0],
+                                                  wpe_table.shape[0], D, n_res, i_decoder, int(elem_bf16), _p(sc), need,
+                                                  _stream()), "mli_paged_decoder_fused")
+
+
+def stream_wait_stream(waiter, signaller):
+    """torch streams: `waiter` waits for everything queued on `signaller` so far (mli_stream_wait_stream)."""
+    _check(load_library().mli_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaller.cuda_stream)),
+           "mli_stream_wait_stream")
+
+
+class StepGraph:
+    """hipGraph of whatever `fn` launches on the current (non-default) stream: mli_graph_* of the C ABI.  Everything
+    `fn` touches must already be allocated (workspaces included): call it once eagerly first."""
+
+    def __init__(self, fn):
+        lib = load_library()
+        stream = _stream()
+        _check(lib.mli_graph_begin_capture(stream), "mli_graph_begin_capture")
+        try:
+            fn()
+        finally:
+            handle = ctypes.c_void_p()
+            rc = lib.mli_graph_end_capture(stream, ctypes.byref(handle))
+        _check(rc, "mli_graph_end_capture")
+        self._exec = handle
+
+    def launch(self):
+        _check(load_library().mli_graph_launch(self._exec, _stream()), "mli_graph_launch")
+
+    def close(self):
+        if self._exec:
+            load_library().mli_graph_destroy(self._exec)
+            self._exec = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- encoder / decoder ---------------------------------------------------------------------

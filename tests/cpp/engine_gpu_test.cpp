@@ -14,6 +14,7 @@
 #include "inference_model.h"
 #include "inferencer.h"
 #include "pipelined_engine.h"
+#include "runtime.h"
 #include "throughput_counter.h"
 
 static std::mt19937 rng(4711);
@@ -79,6 +80,24 @@ int main() {
         std::printf("paged engine: finished %d of %d\n", storage.finish_count(), n_items);
         failures += storage.finish_count() != n_items;
         paged = collect(storage);
+    }
+    // 2b. the same engine with the layers on the reference's launch sequence (scores, probabilities and emb_score
+    //     materialised) instead of the lean compositions: the tokens must not notice
+    std::map<int, std::vector<int>> paged_reference_sequence;
+    {
+        mli::runtime::set_lean_layers(false);
+        ItemStorage storage;
+        ProcessingStorage processing;
+        for (const auto& it : items) storage.add_new_item(IdTokensPair(it));
+        MemoryBlockManager pool(DEFAULT_INIT_NUM_BLOCKS * B, PAGE_BLOCK_SIZE * 3 * D);
+        PagedAttentionsManager pages(B, S, D);
+        PagedAttentionInferenceModel model(PagedAttentionLayer(clone(wk), clone(wq), clone(wv), B, D, S), PagedEncoderLayer(),
+                                           PagedDecoderLayer(B, V), B, S, D, 1);
+        start_paged_attention_inference_engine(emb, pos, storage, processing, pool, pages, model, B, S, 1);
+        mli::runtime::set_lean_layers(true);
+        std::printf("paged engine, materialising layers: finished %d of %d\n", storage.finish_count(), n_items);
+        failures += storage.finish_count() != n_items;
+        paged_reference_sequence = collect(storage);
     }
     // 3. paged "cublas" engine (GemmHandle in place of cublasHandle_t), roomy pool, 2 forward rounds
     std::map<int, std::vector<int>> gemm;
@@ -179,7 +198,9 @@ int main() {
     }
     int mismatched = 0;
     for (const auto& kv : naive)
-        if (paged[kv.first] != kv.second || gemm[kv.first] != kv.second || pipelined[kv.first] != kv.second) ++mismatched;
+        if (paged[kv.first] != kv.second || gemm[kv.first] != kv.second || pipelined[kv.first] != kv.second ||
+            paged_reference_sequence[kv.first] != kv.second)
+            ++mismatched;
     std::printf("items whose tokens differ between engines: %d\n", mismatched);
     failures += mismatched != 0;
     std::printf("%s\n", failures ? "FAILED" : "ALL ENGINES AGREE");

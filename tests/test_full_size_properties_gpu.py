@@ -133,6 +133,49 @@ def test_config4_repeat_is_bit_identical_and_forms_agree(mli, c4):
     assert (wl.attention_result - o0).abs().max().item() <= 1e-5
 
 
+def test_config4_lean_scan_equals_materialising_under_full_load(mli, c4):
+    """The in-kernel merge is a hand-off between workgroups (write-through partials, arrival counter, acquire): it has
+    to hold with every CU streaming and ragged rows finishing at different times, and on repeated launches (the
+    consumer's caches warm with the previous launch's lines at the same addresses).  Every word of attention_result is
+    compared, bit for bit, with the two-launch form -- also with other piece sizes of the rows' remainders, and with
+    lengths that change between launches as they do in a running engine."""
+    from min_llm_inference_amd import ops
+    wl = c4
+    saved = wl.lengths.clone()
+
+    def full():
+        ops.decode_scan_paged(wl.q_output, wl.page_table, wl.lengths, wl.qkt_output, wl.attention_result, True)
+        torch.cuda.synchronize()
+        return wl.attention_result.clone()
+
+    def lean():
+        wl.attention_result.fill_(-7.0)
+        ops.decode_scan_paged(wl.q_output, wl.page_table, wl.lengths, None, wl.attention_result, True, phases=7,
+                              n_sequence=wl.S)
+        torch.cuda.synchronize()
+        return wl.attention_result.clone()
+
+    try:
+        ref = full()
+        for _ in range(4):
+            assert torch.equal(lean(), ref)
+        for tail in (64, 256, 512):
+            assert mli.mli_tune(b"scan_tail_tokens", tail) == 0
+            got = lean()
+            assert (got - ref).abs().max().item() <= 1e-5, tail      # other split points, other merge trees
+            assert torch.equal(got, full()), tail                    # ... but the two forms agree bit for bit
+        mli.mli_tune(b"scan_tail_tokens", 0)
+        g = torch.Generator(device=wl.dev)
+        g.manual_seed(5)
+        for _ in range(3):                                           # shorter rows: other chunk counts per row
+            wl.lengths.copy_((saved.float() * torch.rand(wl.B, device=wl.dev, generator=g)).int().clamp_(min=0))
+            wl.lengths[::97] = 0
+            assert torch.equal(lean(), full())
+    finally:
+        mli.mli_tune(b"scan_tail_tokens", 0)
+        wl.lengths.copy_(saved)
+
+
 def test_config4_rows_of_equal_v_return_that_row(mli, c4):
     """softmax weights sum to one, so a row whose live V rows all equal c gives c (bf16 c, fp32 accumulation)."""
     from min_llm_inference_amd import ops

@@ -1,0 +1,268 @@
+"""GPU parity of what the layers and engines actually run:
+
+* the LEAN single-pass scan -- no raw scores, no probabilities, every row's chunks merged inside the scan launch by the
+  workgroup that completes the row (an inter-workgroup hand-off: write-through stores, arrival counter, acquire) --
+  against the oracle AND bit for bit against the materialising two-launch form on the same inputs;
+* the decoder head with the argmax as the logits GEMM's epilogue (no emb_score) against the oracle's decoder and the
+  materialising launcher: tokens, lengths and the written embeddings must be identical, ties included;
+* a decode step replayed from a hipGraph against the same step launched eagerly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import host, to_dev
+from helpers import (PAGE, assert_close, assert_equal, bf16_bits, bf16_round, build_page_pool, paged_case, rand_f,
+                     rand_i)
+
+pytestmark = pytest.mark.gpu
+
+SENTINEL = 12345.0
+
+
+def _prepare(oracle, dev, seed, B, S, D, **kw):
+    c = paged_case(seed, B, S, D, **kw)
+    oracle.clone_to_pages(c["pool"], c["table"], c["inp_embedding"], c["kt_cache"], c["v_cache"], c["lengths"])
+    return c, to_dev(c, dev)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# (seed, B, S, D): single chunk, several chunks with ragged lengths, wide rows (the waves split the row), odd width
+SCAN_SHAPES = [(131, 24, 256, 512), (132, 9, 1024, 256), (133, 6, 4096, 512), (134, 40, 64, 64), (135, 12, 128, 2048),
+               (136, 7, 2048, 1024), (137, 5, 4096, 1540), (138, 300, 1024, 128)]
+
+
+@pytest.mark.parametrize("merge", [1, 0])
+@pytest.mark.parametrize("seed,B,S,D", SCAN_SHAPES)
+def test_lean_scan_matches_oracle_and_the_materialising_form(oracle, mli, dev, seed, B, S, D, merge):
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=4)
+    # materialising form first (scan + combine launches): the reference's contract, checked elsewhere against the oracle
+    ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], d["qkt_output"], d["attention_result"], False)
+    full = host(d["attention_result"]).copy()
+    d["attention_result"].fill_(SENTINEL)
+    d["qkt_output"].fill_(SENTINEL)
+    assert mli.mli_tune(b"scan_merge", merge) == 0
+    try:
+        for _ in range(3):   # the arrival counters must be back at zero after every launch
+            d["attention_result"].fill_(SENTINEL)
+            ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], None, d["attention_result"], False,
+                                  phases=7, n_sequence=S)
+            assert_equal(host(d["attention_result"]), full, what="lean == materialising, bit for bit")
+    finally:
+        mli.mli_tune(b"scan_merge", 1)
+    assert (host(d["qkt_output"]) == SENTINEL).all(), "lean mode must not touch qkt_output"
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+    assert_close(full, c["attention_result"], what="attention_result vs oracle")
+    assert (full[c["lengths"] == 0] == 0).all()
+
+
+@pytest.mark.parametrize("chunk,tail", [(64, 0), (128, 0), (256, 0), (512, 64), (512, 128), (1024, 256), (256, 256)])
+def test_lean_scan_many_chunks_per_row(oracle, mli, dev, chunk, tail):
+    """Small chunks: up to 64 arrivals per row, rows of every chunk count side by side (uneven load)."""
+    from min_llm_inference_amd import ops
+    B, S, D = 96, 4096, 128
+    rng = np.random.default_rng(140)
+    lengths = rng.integers(0, S, size=B).astype(np.int32)
+    lengths[:8] = [0, 1, chunk - 1, chunk, chunk + 1, S - 1, 2 * chunk, 17]
+    c, d = _prepare(oracle, dev, 141, B, S, D, conditioned=True, lengths=lengths)
+    assert mli.mli_tune(b"chunk_tokens", chunk) == 0
+    assert mli.mli_tune(b"scan_tail_tokens", tail) == 0
+    try:
+        ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], d["qkt_output"], d["attention_result"], False)
+        full = host(d["attention_result"]).copy()
+        for _ in range(2):
+            d["attention_result"].fill_(SENTINEL)
+            ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], None, d["attention_result"], False,
+                                  phases=7, n_sequence=S)
+            assert_equal(host(d["attention_result"]), full, what=f"lean == materialising at {chunk}-token chunks")
+    finally:
+        mli.mli_tune(b"chunk_tokens", 0)
+        mli.mli_tune(b"scan_tail_tokens", 0)
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+    assert_close(full, c["attention_result"], what="attention_result vs oracle")
+    probs = host(d["qkt_output"])       # the materialising form's probabilities under the same item layout
+    assert_close(probs, c["qkt_output"], what="probabilities")
+
+
+@pytest.mark.parametrize("seed,B,S,D", [(151, 128, 64, 512), (152, 40, 208, 1024), (153, 16, 1024, 256), (154, 3, 4096, 512)])
+def test_paged_attention_lean_equals_paged_attention(oracle, mli, dev, seed, B, S, D):
+    """The layers' composition (fill -> latest -> lean scan) leaves the same pages, q_output and attention_result as the
+    reference-shaped one; it just never writes qkt_output."""
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=5)
+    d2 = to_dev(c, dev)
+    ops.paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["q_output"],
+                        d["qkt_output"], d["attention_result"], c["n_new"], S)
+    ops.paged_attention_lean(d2["page_table"], d2["lengths"], d2["wk"], d2["wq"], d2["wv"], d2["new_batch_idx"],
+                             d2["q_output"], d2["attention_result"], c["n_new"], S)
+    assert_equal(host(d2["pool"]), host(d["pool"]), what="page pool")
+    assert_equal(host(d2["q_output"]), host(d["q_output"]), what="q_output")
+    assert_equal(host(d2["attention_result"]), host(d["attention_result"]), what="attention_result")
+    assert_equal(host(d2["qkt_output"]), c["qkt_output"], what="qkt_output untouched")
+    oracle.self_attention_inference_host(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"],
+                                         c["new_batch_idx"], c["kt_cache"], c["v_cache"], c["q_output"],
+                                         c["qkt_output"], c["attention_result"], c["n_new"])
+    assert_close(host(d2["attention_result"]), c["attention_result"], what="attention_result vs oracle")
+
+
+def test_paged_attention_lean_bf16_equals_paged_attention_bf16(mli, dev):
+    from min_llm_inference_amd import ops
+    B, S, D = 48, 1024, 512
+    rng = np.random.default_rng(160)
+    lengths = rng.integers(0, S - 1, size=B).astype(np.int32)
+    lengths[:3] = [0, 1, S - 2]
+    pool, table = build_page_pool(rng, lengths, S, D)
+    pool = ((rng.random(pool.shape, dtype=np.float32) * 2 - 1)).astype(np.float32)
+
+    def state():
+        p = _t(bf16_bits(pool).view(np.int16), dev).view(torch.bfloat16)
+        ptrs = _t(np.where(table >= 0, p.data_ptr() + 2 * table, 0).astype(np.int64), dev)
+        return p, ptrs
+
+    w = [_t(bf16_bits(((rng.random((D, D), dtype=np.float32) * 2 - 1) / np.sqrt(D)).astype(np.float32)).view(np.int16), dev)
+         .view(torch.bfloat16) for _ in range(3)]
+    L = _t(lengths, dev)
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    p1, t1 = state()
+    p2, t2 = state()
+    q1, q2 = torch.zeros(B, D, device=dev), torch.zeros(B, D, device=dev)
+    o1, o2 = torch.zeros(B, D, device=dev), torch.zeros(B, D, device=dev)
+    s1 = torch.zeros(B, S, device=dev)
+    ops.paged_attention_bf16(t1, L, w[0], w[1], w[2], idx, q1, s1, o1, 0, S)
+    ops.paged_attention_lean(t2, L, w[0], w[1], w[2], idx, q2, o2, 0, S)
+    torch.cuda.synchronize()
+    assert torch.equal(p1.view(torch.int16), p2.view(torch.int16)) and torch.equal(q1, q2) and torch.equal(o1, o2)
+    assert torch.isfinite(o2).all() and (o2[0] == 0).all()
+
+
+# ---- decoder head: argmax as the GEMM epilogue -------------------------------------------------------------------
+def _decoder_inputs(rng, B, S, D, V):
+    emb = (rng.random((V, D), dtype=np.float32) * 2 - 1).astype(np.float32)
+    wpe = rand_f(rng, (S, D))
+    att = (rng.random((B, D), dtype=np.float32) * 2 - 1).astype(np.float32)
+    lengths = rand_i(rng, (B,), S - 2)
+    lengths[:4] = [0, S - 1, S - 2, 1]            # empty slot, finishes on length, last writable position, first token
+    att[5] = 1.0
+    emb[1023, :] = 2.0                            # row 5 is pushed onto EOF
+    # ties: identical embedding rows give identical logits; the LOWER index must win, within a 64-column tile
+    # (70 vs 75), across tiles of one workgroup row (3 vs 700) and against the last, partial tile
+    emb[75] = emb[70]
+    emb[700] = emb[3]
+    last = V - 1 if V - 1 != 1023 else V - 2     # (never the EOF row)
+    emb[last] = emb[130]
+    att[6] = emb[70] * 4
+    att[7] = emb[3] * 4
+    att[8] = emb[130] * 4
+    return emb, wpe, att, lengths
+
+
+@pytest.mark.parametrize("seed,B,S,D,V", [(161, 64, 128, 132, 1500), (162, 200, 64, 512, 1024), (163, 12, 4096, 64, 1025),
+                                          (164, 1024, 64, 256, 1024)])
+def test_decoder_fused_contiguous(oracle, mli, dev, seed, B, S, D, V):
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    emb, wpe, att, lengths = _decoder_inputs(rng, B, S, D, V)
+    inp_emb = rand_f(rng, (B, S, D))
+    score = np.zeros((B, V), np.float32)
+    res = np.full((B,), 77, np.int32)
+    d_inp, d_len, d_res = _t(inp_emb, dev), _t(lengths, dev), _t(res, dev)
+    ops.decoder_fused(_t(att, dev), _t(emb, dev), _t(wpe, dev), d_inp, d_len, d_res)
+    # the materialising launcher on the same inputs
+    m_inp, m_len, m_res, m_score = _t(inp_emb, dev), _t(lengths, dev), _t(res, dev), _t(score, dev)
+    ops.launch_decoder(_t(att, dev), _t(emb, dev), m_score, _t(wpe, dev), m_inp, m_len, m_res)
+    oracle.decoder_host(att, emb, score, wpe, inp_emb, lengths, res)
+    assert_equal(host(d_res), host(m_res), what="tokens: fused == materialising")
+    assert_equal(host(d_res), res, what="decoder_result vs oracle")
+    assert_equal(host(d_len), lengths, what="lengths")
+    assert_equal(host(d_inp), inp_emb, what="inp_embedding (next token rows; everything else untouched)")
+    assert res[0] == -1 and lengths[0] == 0 and lengths[1] == 0 and res[5] == 1023 and lengths[5] == 0
+    assert res[6] == 70 and res[7] == 3 and res[8] == 130, "ties go to the lowest index"
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("seed,B,S,D,V", [(165, 64, 128, 136, 1500), (166, 100, 256, 512, 1024), (167, 1024, 64, 512, 1024)])
+def test_decoder_fused_paged_multi_rounds(oracle, mli, dev, seed, B, S, D, V, bf16):
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    emb, wpe, att, lengths = _decoder_inputs(rng, B, S, D, V)
+    pool, table = build_page_pool(rng, lengths, S, D)
+    n_rounds, i_dec = 3, 1
+    score = np.zeros((B, V), np.float32)
+    res = np.full((B, n_rounds), 77, np.int32)
+
+    def state():
+        if bf16:
+            p = _t(bf16_bits(pool).view(np.int16), dev).view(torch.bfloat16)
+            ptrs = _t(np.where(table >= 0, p.data_ptr() + 2 * table, 0).astype(np.int64), dev)
+        else:
+            p = _t(pool, dev)
+            ptrs = _t(np.where(table >= 0, p.data_ptr() + 4 * table, 0).astype(np.int64), dev)
+        return p, ptrs, _t(lengths, dev), _t(res, dev)
+
+    p1, t1, l1, r1 = state()
+    p2, t2, l2, r2 = state()
+    ops.paged_decoder_fused(_t(att, dev), _t(emb, dev), _t(wpe, dev), t1, l1, r1, i_dec, bf16)
+    m_score = _t(score, dev)
+    fn = ops.launch_paged_attention_decoder_multi_rounds_bf16 if bf16 else ops.launch_paged_attention_decoder_multi_rounds
+    fn(_t(att, dev), _t(emb, dev), m_score, _t(wpe, dev), t2, l2, r2, i_dec)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(l1, l2), "tokens / lengths: fused == materialising"
+    assert torch.equal(p1.view(torch.int16 if bf16 else torch.int32), p2.view(torch.int16 if bf16 else torch.int32))
+    if not bf16:
+        oracle.paged_decoder_host(att, emb, score, wpe, pool, table, lengths, res, i_dec)
+        assert_equal(host(r1), res, what="decoder_result vs oracle")
+        assert_equal(host(l1), lengths, what="lengths vs oracle")
+        assert_equal(host(p1), pool, what="page pool (next embeddings in segment 0; everything else untouched)")
+    got = host(r1)
+    assert (got[:, [0, 2]] == 77).all() and got[6, i_dec] == 70 and got[7, i_dec] == 3 and got[8, i_dec] == 130
+
+
+def test_decoder_fused_needs_its_scratch(mli, dev):
+    from min_llm_inference_amd import _lib
+    z = torch.zeros(4, 64, device=dev)
+    i4 = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = mli.mli_decoder_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), i4.data_ptr(), i4.data_ptr(),
+                               4, 64, 64, 64, None, 0, None)
+    assert rc == -12  # MLI_ERR_WORKSPACE
+
+
+# ---- a decode step replayed from a hipGraph ----------------------------------------------------------------------
+@pytest.mark.parametrize("bf16", [False, True])
+def test_graph_replay_equals_eager_steps(mli, dev, bf16):
+    """N decode steps (lean attention + fused decoder head) launched eagerly == the same N steps replayed from ONE
+    captured hipGraph: lengths advance on the device, so every replay does different work through the same nodes."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from min_llm_inference_amd import ops
+    n_steps = 6
+
+    def run(graph):
+        wl = bench.Workload("c3", dev, 0xABCD, headroom=n_steps + 8, dtype="bf16" if bf16 else "f32")
+        toks = []
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            step = wl.lean_step
+            step()                                   # warm-up: allocates the per-stream workspaces
+            toks.append(wl.decoder_result.clone())
+            g = ops.StepGraph(step) if graph else None
+            for _ in range(n_steps):
+                g.launch() if graph else step()
+                toks.append(wl.decoder_result.clone())
+            side.synchronize()
+        return torch.stack(toks).cpu().numpy(), wl.lengths.cpu().numpy(), wl.attention_result.cpu().numpy()
+
+    t0, l0, a0 = run(False)
+    t1, l1, a1 = run(True)
+    assert_equal(t1, t0, what="tokens per step")
+    assert_equal(l1, l0, what="lengths")
+    assert_equal(a1, a0, what="attention_result of the last step")
+    assert (t0 >= 0).all() and len(np.unique(t0)) > 4
