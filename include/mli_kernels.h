@@ -249,6 +249,25 @@ int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, c
                             int n_decoder_results, int i_decoder, int elem_bf16,
                             void* scratch, size_t scratch_bytes, void* stream);
 
+/* One whole decode step of the continuous batch (n_new_items = 0) in ONE call: what *InferenceModel::forward does per
+ * round once the new rows are prefilled (reference src/inference_model.cpp:26-30, 68-72) -- lean attention
+ * (mli_paged_attention_lean / mli_inference_self_attention) followed by the fused decoder head.  For hosts that pay per
+ * call (the Python test / bench front end); the C++ layers issue the same launches themselves.
+ *   paged:      q_output [n_batch, emb_dim] is scratch; attention_result [n_batch, emb_dim] holds the attention output
+ *   contiguous: qkt_output [n_batch, n_sequence] is scratch as well (K^T and V are two passes) */
+int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk, const void* wq, const void* wv,
+                          const float* emb_table, const float* wpe_table, float* q_output, float* attention_result,
+                          int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
+                          int n_decoder_results, int i_decoder, int elem_bf16,
+                          void* workspace, size_t workspace_bytes, void* decoder_scratch, size_t decoder_scratch_bytes,
+                          void* stream);
+int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const float* wq, const float* wv,
+                    const float* emb_table, const float* wpe_table, float* kt_cache, float* v_cache,
+                    float* q_output, float* qkt_output, float* attention_result, int* decoder_result,
+                    int n_batch, int n_sequence, int emb_dim, int n_vocab,
+                    void* workspace, size_t workspace_bytes, void* decoder_scratch, size_t decoder_scratch_bytes,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------
  * hipGraph capture of a decode step.  No entry point above allocates or synchronises, so any sequence of them issued
  * on one (non-default) stream between begin and end becomes a graph; replaying it costs one host call instead of one
@@ -288,7 +307,7 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "scan_partial_last" 1 (default) = the single-pass scan runs full chunks first and every row's remainder behind
  *                      them, cut into pieces of "scan_tail_tokens" tokens (what is still running when the queue runs
  *                      dry is short), 0 = plain chunk order
- *   "scan_tail_tokens" 0 (default) = 128, else a power of two in [64, chunk]: the size of those pieces
+ *   "scan_tail_tokens" 0 (default) = the remainder stays one piece, else a power of two in [64, chunk]: piece size
  *   "scan_merge"       (lean mode) 1 (default) = the workgroup that completes a row merges its chunks inside the scan
  *                      launch, 0 = a separate combine launch; bit-identical results
  *   "scan_dynamic_items" 1 = the single-pass scan hands its (row, chunk) items out through a ticket counter (balances
@@ -301,6 +320,10 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
  *                      (zeros for the empty ones); bit-identical results
  *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
+ *   "gemm_panel"       1 (default) = small fp32 products (emb_dim <= 512, fewer than 256 tiles of 64x64: the decode
+ *                      projection and the logits of configs 2 / 3) run the latency-shaped kernel (32x32 tiles, the
+ *                      whole K panel requested at once), 0 = always the tiled kernel, 2 = whenever the shape allows
+ *                      (lets tests push other shapes through it); bit-identical results
  *   "gemm_tall_tiles"  1 (default) = 128x64 workgroup tiles for the decode projection / logits GEMM (fp32 and bf16)
  *                      when the grid still fills the chip, 0 = always 64x64, 2 = 128x64 whenever the mode allows it
  *                      (lets small test shapes exercise that kernel)

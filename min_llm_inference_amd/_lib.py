@@ -66,6 +66,8 @@ SIGNATURES = {
     "mli_decoder_scratch_bytes": [_I, _I],
     "mli_decoder_fused": [_P] * 6 + [_I] * 4 + [_P, _Z, _P],
     "mli_paged_decoder_fused": [_P] * 6 + [_I] * 7 + [_P, _Z, _P],
+    "mli_paged_decode_step": [_P] * 10 + [_I] * 7 + [_P, _Z, _P, _Z, _P],
+    "mli_decode_step": [_P] * 13 + [_I] * 4 + [_P, _Z, _P, _Z, _P],
     "mli_graph_begin_capture": [_P],
     "mli_graph_end_capture": [_P, ctypes.POINTER(ctypes.c_void_p)],
     "mli_graph_launch": [_P, _P],

@@ -136,6 +136,32 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     }
 #endif
     MLI_TRACE(0);
+    // Prologue chain: lengths[b] -> page pointers -> first K rows, each hop a memory round trip during which this
+    // workgroup's share of the CU streams nothing.  Where the item's first token does not depend on the length (the
+    // full-chunk grid rows) the pointers -- and q -- are requested BEFORE the length is waited for: one hop less.
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int W = S / kPage;
+    const bool early = !tail || c < nchunk_max;
+    const void* early_ptr = nullptr;
+    if (early && (int)threadIdx.x < ct / kPage && c * (ct / kPage) + (int)threadIdx.x < W)
+        early_ptr = page_table[(int64_t)b * W + c * (ct / kPage) + threadIdx.x];
+    constexpr int EPLc = E::EPL;
+    const int Du = D / EPLc;  // lane-units per row
+    // q in registers (NJ * EPL floats per lane), zero beyond the row
+    float qr[NJ][EPLc];
+    bool live[NJ];
+    unsigned voff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int u = (DS ? wave * NJ * kWave : 0) + lane + j * kWave;
+        live[j] = u < Du;
+        // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
+        // them, so the loads need no per-lane predication
+        voff[j] = live[j] ? (unsigned)u * 16u : 0x40000000u;
+#pragma unroll
+        for (int e = 0; e < EPLc; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPLc + e] : 0.f;
+    }
     const int L = min(lengths[b], S);
     if (arrivals != nullptr && L == 0) {
         // in-kernel merge: no workgroup arrives for an empty row, so its zero result is written here, once
@@ -159,8 +185,6 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
             c = nf + (c - nchunk_max);          // its slot among the row's items
         }
     }
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
     float* qkt_row = qkt + (int64_t)b * S;
 
     if (s0 >= L) {
@@ -172,30 +196,18 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     }
     const int ntok = s1 - s0;
     const int npages = (ntok + kPage - 1) / kPage;
-    for (int i = threadIdx.x; i < npages; i += (WAVES * kWave))
-        ptr_sh[i] = page_table[(int64_t)b * (S / kPage) + s0 / kPage + i];
+    if (early) {
+        if ((int)threadIdx.x < npages) ptr_sh[threadIdx.x] = early_ptr;   // npages <= ct / 16 <= 64 < threads
+    } else {
+        for (int i = threadIdx.x; i < npages; i += (WAVES * kWave))
+            ptr_sh[i] = page_table[(int64_t)b * W + s0 / kPage + i];
+    }
     __syncthreads();
     MLI_TRACE(1);
 
-    const int Du = D / EPL;  // lane-units per row
     const float scale = sqrtf((float)D);
     const int64_t row_bytes = (int64_t)3 * D * E::kBytes;  // consecutive token slots of a page
     const int64_t seg_bytes = (int64_t)D * E::kBytes;      // segment stride inside a slot: x | K | V
-
-    // q in registers (NJ * EPL floats per lane), zero beyond the row
-    float qr[NJ][EPL];
-    bool live[NJ];
-    unsigned voff[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int u = (DS ? wave * NJ * kWave : 0) + lane + j * kWave;
-        live[j] = u < Du;
-        // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
-        // them, so the loads need no per-lane predication
-        voff[j] = live[j] ? (unsigned)u * 16u : 0x40000000u;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPL + e] : 0.f;
-    }
 
     float run_m = -INFINITY, run_l = 0.f;
     float acc[NJ][EPL];
@@ -520,8 +532,10 @@ static int g_flash_variant = 0;  // register-budget variants of the scan kernel 
 // "scan_tail_tokens" tokens; 0 = plain chunk order
 static int g_partial_last = 1;
 void set_partial_last(int v) { g_partial_last = v != 0; }
-// mli_tune "scan_tail_tokens": 0 (default) = 128-token pieces (the whole remainder as one piece when the chunk is not
-// larger than that), else a power of two in [64, chunk]
+// mli_tune "scan_tail_tokens": 0 (default) = the whole remainder as one piece, else a power of two in [64, chunk].
+// Measured at config 4 (bf16, 512-token chunks, lean form): one piece 658.7 us, 256-token pieces 661.9, 128: 668.7,
+// 64: 688.0 -- every item costs about 2.5 us of a workgroup slot (prologue chain lengths -> page pointers -> first K
+// rows, epilogue merge and publication), more than the shorter end of the launch gives back.
 static int g_tail_tokens = 0;
 void set_tail_tokens(int v) { g_tail_tokens = v; }
 // mli_tune "scan_dynamic_items": ticketed (row, chunk) assignment.  Off by default: it shortens the kernel by 0.6-1.5 %
@@ -600,12 +614,13 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     // tail > 0: full chunks first, the remainders behind them in pieces of `tail` tokens (slots = triples per row)
     int tail = 0, slots = nchunk;
     if (!direct && ticket == nullptr && g_partial_last) {
-        tail = g_tail_tokens ? g_tail_tokens : 128;
+        tail = g_tail_tokens ? g_tail_tokens : ct;
         if (tail > ct || tail < 64 || (tail & (tail - 1))) tail = ct;
-        // (the workspace is sized for 64-token chunks: room for every layout with fewer items per row than that)
-        if (nchunk + ct / tail > ml_per_row) tail = ct;
-        slots = nchunk + ct / tail;
-        grid = dim3(B, slots);
+        // a row with a remainder has at most nchunk - 1 full chunks: nchunk + pieces - 1 triples per row at most (the
+        // workspace is sized for 64-token chunks: room for every layout with no more items per row than that)
+        if (nchunk + ct / tail - 1 > ml_per_row) tail = ct;
+        slots = nchunk + ct / tail - 1;
+        grid = dim3(B, nchunk + ct / tail);
         if ((size_t)B * slots * D * sizeof(float) + stats_bytes > ws_bytes) return 0;
     }
     const bool nt = nt_loads_enabled();

@@ -24,6 +24,7 @@ void set_bf16_native_mfma(int v);  // proj_gemm.hip
 void set_flash_decode(int v);      // attention_fused.hip
 void set_flash_variant(int v);
 void set_scan_merge(int v);
+void set_gemm_panel(int v);
 void set_tail_tokens(int v);
 void set_dynamic_items(int v);
 void set_partial_last(int v);
@@ -680,6 +681,8 @@ int mli_tune(const char* key, int value) {
         mli::set_latest_compact(value);
     } else if (k == "fill_compact") {
         mli::set_fill_compact(value);
+    } else if (k == "gemm_panel") {
+        mli::set_gemm_panel(value);
     } else if (k == "gemm_deep_k") {
         mli::set_deep_k_tiles(value);
     } else if (k == "gemm_tall_tiles") {

@@ -73,6 +73,33 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths, const 
     return fused < 0 ? fused : fused - 1;
 }
 
+int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk, const void* wq, const void* wv,
+                          const float* emb_table, const float* wpe_table, float* q_output, float* attention_result,
+                          int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
+                          int n_decoder_results, int i_decoder, int elem_bf16, void* workspace, size_t workspace_bytes,
+                          void* decoder_scratch, size_t decoder_scratch_bytes, void* stream) {
+    const int rc = mli_paged_attention_lean(page_table, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, q_output,
+                                            attention_result, n_batch, n_sequence, emb_dim, /*n_new_items=*/0, elem_bf16,
+                                            workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return mli_paged_decoder_fused(attention_result, emb_table, wpe_table, page_table, lengths, decoder_result, n_batch,
+                                   n_vocab, n_sequence, emb_dim, n_decoder_results, i_decoder, elem_bf16, decoder_scratch,
+                                   decoder_scratch_bytes, stream);
+}
+
+int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const float* wq, const float* wv,
+                    const float* emb_table, const float* wpe_table, float* kt_cache, float* v_cache, float* q_output,
+                    float* qkt_output, float* attention_result, int* decoder_result, int n_batch, int n_sequence,
+                    int emb_dim, int n_vocab, void* workspace, size_t workspace_bytes, void* decoder_scratch,
+                    size_t decoder_scratch_bytes, void* stream) {
+    const int rc = mli_inference_self_attention(inp_embedding, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, kt_cache,
+                                                v_cache, q_output, qkt_output, attention_result, n_batch, n_sequence,
+                                                emb_dim, emb_dim, /*n_new_items=*/0, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return mli_decoder_fused(attention_result, emb_table, wpe_table, inp_embedding, lengths, decoder_result, n_batch,
+                             n_vocab, n_sequence, emb_dim, decoder_scratch, decoder_scratch_bytes, stream);
+}
+
 int mli_graph_begin_capture(void* stream) {
     if (stream == nullptr) return MLI_ERR_BAD_ARG;  // the legacy default stream cannot be captured
     return (int)hipStreamBeginCapture(mli::as_stream(stream), hipStreamCaptureModeThreadLocal);

@@ -10,8 +10,9 @@
 namespace mli {
 
 int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int K, hipStream_t st);
-int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, hipStream_t st);
-int gemm_nt_argmax_tiles(int N);
+int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, int* n_tiles,
+                          hipStream_t st);
+int gemm_nt_argmax_max_tiles(int N);
 
 constexpr int kEdThreads = 256;
 
@@ -280,7 +281,7 @@ int mli_paged_decoder_multi_rounds(const float* batch_result, const float* emb_t
 
 size_t mli_decoder_scratch_bytes(int n_batch, int n_vocab) {
     if (n_batch <= 0 || n_vocab <= 0) return 0;
-    return (size_t)n_batch * mli::gemm_nt_argmax_tiles(n_vocab) * sizeof(mli::RowBest);
+    return (size_t)n_batch * mli::gemm_nt_argmax_max_tiles(n_vocab) * sizeof(mli::RowBest);
 }
 
 // layout: 0 = contiguous (inp_embedding), 1 = paged fp32, 2 = paged bf16
@@ -294,9 +295,9 @@ static int decoder_fused(int layout, const float* batch_result, const float* emb
     if (scratch == nullptr || scratch_bytes < mli_decoder_scratch_bytes(n_batch, n_vocab)) return MLI_ERR_WORKSPACE;
     hipStream_t st = mli::as_stream(stream);
     mli::RowBest* best = reinterpret_cast<mli::RowBest*>(scratch);
-    int rc = mli::launch_gemm_nt_argmax(batch_result, emb_table, best, n_batch, n_vocab, emb_dim, st);
+    int n_tiles = 0;
+    int rc = mli::launch_gemm_nt_argmax(batch_result, emb_table, best, n_batch, n_vocab, emb_dim, &n_tiles, st);
     if (rc) return rc;
-    const int n_tiles = mli::gemm_nt_argmax_tiles(n_vocab);
     const dim3 grid(mli::ceil_div_i(n_batch, mli::kFinalizeRows)), block(mli::kEdThreads);
     if (layout == 0)
         hipLaunchKernelGGL((mli::decoder_finalize_kernel<false>), grid, block, 0, st, best, n_tiles, decoder_result, lengths,

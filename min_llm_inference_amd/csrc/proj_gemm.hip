@@ -336,10 +336,20 @@ static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v < 0 ? 0 : (v > 2 ? 2 : v); }
 bool gemm_use_tall_tiles(int64_t tall_workgroups) { return g_gemm_tall_tiles == 2 || (g_gemm_tall_tiles == 1 && tall_workgroups >= 512); }
 
+// proj_gemm_panel.hip: the latency-shaped kernel for small decode-step products
+bool gemm_panel_wanted(int M, int N_total, int K, bool vec4);
+int gemm_panel_tiles_n(int N);
+template <int MODE, bool BT>
+int launch_gemm_panel(const GemmArgs& g, int rows, hipStream_t st);
+
 // rows = live extent of the M dimension (per z-slice)
 template <int MODE, bool BT>
 static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_t st) {
     if (g.N <= 0 || g.K <= 0 || rows <= 0 || z <= 0) return MLI_ERR_BAD_ARG;
+    constexpr bool kPanelMode = ((MODE == kPagedLatest || MODE == kNaiveLatest) && !BT) || (MODE == kPlain && BT);
+    if constexpr (kPanelMode) {
+        if (z == 1 && gemm_panel_wanted(rows, g.N * g.n_out, g.K, vec4)) return launch_gemm_panel<MODE, BT>(g, rows, st);
+    }
     const int tiles_x = ceil_div_i(g.N, BN) * g.n_out;
     // 128-row tiles when they still fill the chip (>= 2 workgroups per CU) -- decode projection / logits of a large
     // batch; the prefill fill keeps 64-row tiles (a new row's prompt rarely fills 128 rows)
@@ -472,9 +482,15 @@ int launch_gemm_nt(const float* A, const float* Bt, float* C, int M, int N, int 
 
 // The same product with the argmax epilogue: nothing of C[M, N] is stored, row_best[m][t] = (max, lowest index of the
 // max) over the columns of tile t.  Tiles per row: gemm_nt_argmax_tiles(N).
-int gemm_nt_argmax_tiles(int N) { return ceil_div_i(N, BN); }
-int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, hipStream_t st) {
+// (the panel kernel's tiles are 32 columns wide, the tiled kernel's 64: n_tiles tells the caller which ran)
+int gemm_nt_argmax_max_tiles(int N) { return ceil_div_i(N, 32); }
+int launch_gemm_nt_argmax(const float* A, const float* Bt, RowBest* row_best, int M, int N, int K, int* n_tiles,
+                          hipStream_t st) {
     if (M <= 0 || row_best == nullptr) return MLI_ERR_BAD_ARG;
+    {
+        const bool vec4 = K % 4 == 0 && aligned16(A) && aligned16(Bt);
+        *n_tiles = gemm_panel_wanted(M, N, K, vec4) ? gemm_panel_tiles_n(N) : ceil_div_i(N, BN);
+    }
     GemmArgs g{};
     g.w[0] = Bt; g.n_out = 1; g.out_id[0] = 1;
     g.M = M; g.N = N; g.K = K;

@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from ._lib import MliError, load_library
+from ._lib import MliError, load_library  # noqa: F401  (re-exported: ops.MliError, ops.load_library)
 
 PAGE_BLOCK_SIZE = 16
 EMPTY_ROW_TOKEN_ID = -1

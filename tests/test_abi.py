@@ -43,8 +43,8 @@ def test_abi_version_and_workspace_query(mli):
     # [row arrival counters: 64 KiB, fixed][chunk statistics, padded to 256 bytes][partial sums]
     assert mli.mli_attention_workspace_bytes(4, 64, 64) == 65536 + 256   # single chunk: no partial sums
     assert mli.mli_attention_workspace_bytes(1024, 4096, 512) == 65536 + 1024 * 64 * 8 + 1024 * 64 * 512 * 4
-    assert mli.mli_decoder_scratch_bytes(1024, 1024) == 1024 * 16 * 8  # one (value, index) pair per row and 64-column tile
-    assert mli.mli_decoder_scratch_bytes(3, 65) == 3 * 2 * 8
+    assert mli.mli_decoder_scratch_bytes(1024, 1024) == 1024 * 32 * 8  # a (value, index) pair per row and 32-column tile
+    assert mli.mli_decoder_scratch_bytes(3, 65) == 3 * 3 * 8
     assert mli.mli_attention_workspace_bytes(0, 4096, 512) == 0
 
 

@@ -266,3 +266,71 @@ def test_graph_replay_equals_eager_steps(mli, dev, bf16):
     assert_equal(l1, l0, what="lengths")
     assert_equal(a1, a0, what="attention_result of the last step")
     assert (t0 >= 0).all() and len(np.unique(t0)) > 4
+
+
+# ---- the latency-shaped small GEMM (proj_gemm_panel.hip) ----------------------------------------------------------
+@pytest.mark.parametrize("seed,B,S,D", [(171, 256, 1024, 256), (172, 37, 128, 132), (173, 64, 256, 516), (174, 300, 64, 64),
+                                        (175, 5, 128, 1024)])
+def test_panel_projection_bit_identical_to_the_tiled_kernel(oracle, mli, dev, seed, B, S, D):
+    """get_latest (paged and contiguous) through the 32x32-tile, whole-K-panel kernel == through the 64x64 tiled one,
+    bit for bit (both are k-ordered fp32 fma chains), and both match the oracle; rows the op must not touch stay
+    untouched.  The engines need the identity: prefill (tiled) and decode (panel) must write the same K / V rows."""
+    from min_llm_inference_amd import ops
+    from helpers import naive_case
+    c, _ = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=5)
+    n = naive_case(seed + 7, B, S, D, D, conditioned=True, zero_every=5)
+    n["lengths"] = np.maximum(n["lengths"] - 1, 0).astype(np.int32)   # get_latest reads position L - 1
+    results = {}
+    for mode in (0, 2):
+        assert mli.mli_tune(b"gemm_panel", mode) == 0
+        try:
+            d = to_dev(c, dev)
+            ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"],
+                                                        d["q_output"], S)
+            dn = {k: _t(v, dev) for k, v in n.items() if isinstance(v, np.ndarray)}
+            ops.launch_get_latest_kt_q_v(dn["inp"], dn["lengths"], dn["wk"], dn["wq"], dn["wv"], dn["kt_cache"],
+                                         dn["v_cache"], dn["q_output"])
+            results[mode] = [host(d["pool"]).copy(), host(d["q_output"]).copy(), host(dn["kt_cache"]).copy(),
+                             host(dn["v_cache"]).copy(), host(dn["q_output"]).copy()]
+        finally:
+            mli.mli_tune(b"gemm_panel", 1)
+    for a, b, what in zip(results[0], results[2], ["page pool", "q_output (paged)", "kt_cache", "v_cache", "q_output"]):
+        assert_equal(b, a, what=f"{what}: panel == tiled")
+    oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
+                             c["q_output"])
+    assert_close(results[2][1], c["q_output"], what="q_output vs oracle")
+    oracle.get_latest_kt_q_v(n["inp"], n["lengths"], n["wk"], n["wq"], n["wv"], n["kt_cache"], n["v_cache"], n["q_output"])
+    assert_close(results[2][2], n["kt_cache"], what="kt_cache vs oracle")
+    assert_close(results[2][3], n["v_cache"], what="v_cache vs oracle")
+    assert_close(results[2][4], n["q_output"], what="q_output (contiguous) vs oracle")
+
+
+@pytest.mark.parametrize("seed,B,S,D,V", [(176, 256, 128, 256, 1024), (177, 64, 128, 132, 1500), (178, 9, 64, 512, 1025)])
+def test_panel_logits_and_argmax_equal_the_tiled_kernel(oracle, mli, dev, seed, B, S, D, V):
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    emb, wpe, att, lengths = _decoder_inputs(rng, max(B, 9), S, D, V)
+    emb, att, lengths = emb, att[:max(B, 9)], lengths[:max(B, 9)]
+    Bn = att.shape[0]
+    inp_emb = rand_f(rng, (Bn, S, D))
+    out = {}
+    for mode in (0, 2):
+        assert mli.mli_tune(b"gemm_panel", mode) == 0
+        try:
+            d_inp, d_len, d_res = _t(inp_emb, dev), _t(lengths, dev), _t(np.full((Bn,), 77, np.int32), dev)
+            ops.decoder_fused(_t(att, dev), _t(emb, dev), _t(wpe, dev), d_inp, d_len, d_res)
+            m_inp, m_len, m_res = _t(inp_emb, dev), _t(lengths, dev), _t(np.full((Bn,), 77, np.int32), dev)
+            m_score = torch.zeros(Bn, V, device=dev)
+            ops.launch_decoder(_t(att, dev), _t(emb, dev), m_score, _t(wpe, dev), m_inp, m_len, m_res)
+            out[mode] = [host(d_res).copy(), host(d_len).copy(), host(d_inp).copy(), host(m_score).copy(), host(m_res).copy()]
+        finally:
+            mli.mli_tune(b"gemm_panel", 1)
+    for a, b, what in zip(out[0], out[2], ["tokens (fused)", "lengths", "inp_embedding", "emb_score", "tokens (materialising)"]):
+        assert_equal(b, a, what=f"{what}: panel == tiled")
+    assert_equal(out[2][0], out[2][4], what="fused == materialising tokens")
+    score = np.zeros((Bn, V), np.float32)
+    res = np.full((Bn,), 77, np.int32)
+    L = lengths.copy()
+    oracle.decoder_host(att, emb, score, wpe, inp_emb.copy(), L, res)
+    assert_equal(out[2][0], res, what="tokens vs oracle")
+    assert_close(out[2][3], score, what="emb_score vs oracle")
