@@ -402,6 +402,7 @@ def run_engine_mode(args, rank, world, dev):
     figure README.md:54-82 quotes (123 284 tok/s on an unnamed NVIDIA GPU).  Each rank runs an independent
     replica of the workload on its own GPU."""
     from min_llm_inference_amd import engine as eng
+    ops.load_library().mli_engine_set_lean_layers(0 if args.reference_launch_sequence else 1)
     _, B, D, S = WORKLOADS[args.workload if args.workload != "c4" or args.engine_shape else "e1"]
     V = N_VOCAB
     rng = np.random.default_rng(0x5EED0100 + rank)
@@ -511,6 +512,9 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU work: start the ranks, rendezvous over gloo, print one line (tests the launch path on CPU)")
+    ap.add_argument("--reference-launch-sequence", action="store_true",
+                    help="engine mode: the layers issue the reference's launch sequence (encoder, fill, latest, scan + "
+                         "combine, logits, argmax) instead of the lean compositions; same tokens")
     ap.add_argument("--reference-quirk", action="store_true",
                     help="engine mode: reproduce the reference's stale-length upload (DESIGN.md deviation 2)")
     args = ap.parse_args()
@@ -581,6 +585,7 @@ def main():
                                        "host scheduling, prefill, page growth and preemption",
                            "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
                            "reference_length_reset_quirk": bool(args.reference_quirk),
+                           "layers": "reference launch sequence" if args.reference_launch_sequence else "lean compositions",
                            "total_tokens": tok.item(), "seconds": sec.item()}}))
         if world > 1:
             dist.destroy_process_group()
@@ -684,7 +689,8 @@ def engine_config(args, dev):
     in a child process so that the engine's allocations and host threads never share this process's timed region."""
     import subprocess
     out = {}
-    for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_pipelined", ["--pipelined"])):
+    for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_pipelined", ["--pipelined"]),
+                         ("e1_f32_paged_gemm_reference_launch_sequence", ["--reference-launch-sequence"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "engine", "--gpus", "1", *extra]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

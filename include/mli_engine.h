@@ -83,6 +83,12 @@ int mli_engine_decoder_result(mli_engine* engine, void** device_ptr, int* count)
 /* Finished item `index` (0 <= index < stats.finished), in completion order: id and tokens (prompt + generated). */
 int mli_engine_get_finished(mli_engine* engine, int index, int* id, int* tokens, int capacity, int* n_tokens);
 
+/* Process-wide: 1 (default) = the models' layers run the lean compositions (prefill with the encoder as the fill GEMM's
+ * prologue, attention without materialised scores / probabilities, decoder head with the argmax as the logits GEMM's
+ * epilogue), 0 = the reference's launch sequence (encoder, fill, latest, scan + combine, logits, argmax).  Tokens are
+ * identical either way; the switch exists to measure one against the other. */
+void mli_engine_set_lean_layers(int enabled);
+
 const char* mli_engine_last_error(void);
 
 #ifdef __cplusplus

@@ -249,6 +249,22 @@ int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, c
                             int n_decoder_results, int i_decoder, int elem_bf16,
                             void* scratch, size_t scratch_bytes, void* stream);
 
+/* PREFILL of the newly inserted rows in ONE launch: the encoder as the fill GEMM's prologue.  The A
+ * tile rows are computed on the fly as emb_table[inp[b, s]] + wpe[s] -- nothing is read back from the input-embedding
+ * segment -- multiplied by [Wk | Wv], and the workgroups of the first column tile also write those rows to segment 0
+ * (the decode projection reads position L - 1 from there).  Pages / caches come out bit-identical to
+ *   mli_paged_attention_encoder[_bf16] + mli_fill_new_k_v_cache_paged[_bf16]   (paged; elem_bf16 selects the element type)
+ *   mli_inference_optimized_encoder + mli_fill_new_kt_v_cache                   (contiguous)
+ * i.e. launch_paged_attention_encoder_kernel + launch_fill_new_k_v_cache_paged_attention[_warp_tiling]
+ * (encoder.h:22-25, paged_attention.h:28-30,65-67) resp. launch_inference_optimized_encoder_kernel +
+ * launch_fill_new_kt_v_cache (encoder.h:16-19, self_attention_inference_optimized.h:5-8).  No-op when n_new_items == 0. */
+int mli_paged_prefill(const float* emb_table, const float* wpe, const int* inp, void* const* page_table,
+                      const int* lengths, const int* new_item_indices, const void* wk, const void* wv,
+                      int n_batch, int n_sequence, int emb_dim, int n_new_items, int elem_bf16, void* stream);
+int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float* inp_embedding, const int* lengths,
+                const int* new_item_indices, const float* wk, const float* wv, float* kt_cache, float* v_cache,
+                int n_batch, int n_sequence, int input_dim, int output_dim, int n_new_items, void* stream);
+
 /* One whole decode step of the continuous batch (n_new_items = 0) in ONE call: what *InferenceModel::forward does per
  * round once the new rows are prefilled (reference src/inference_model.cpp:26-30, 68-72) -- lean attention
  * (mli_paged_attention_lean / mli_inference_self_attention) followed by the fused decoder head.  For hosts that pay per

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mli_decoder_scratch_bytes": [_I, _I],
     "mli_decoder_fused": [_P] * 6 + [_I] * 4 + [_P, _Z, _P],
     "mli_paged_decoder_fused": [_P] * 6 + [_I] * 7 + [_P, _Z, _P],
+    "mli_paged_prefill": [_P] * 8 + [_I] * 5 + [_P],
+    "mli_prefill": [_P] * 10 + [_I] * 5 + [_P],
     "mli_paged_decode_step": [_P] * 10 + [_I] * 7 + [_P, _Z, _P, _Z, _P],
     "mli_decode_step": [_P] * 13 + [_I] * 4 + [_P, _Z, _P, _Z, _P],
     "mli_graph_begin_capture": [_P],
@@ -106,10 +108,11 @@ ENGINE_SIGNATURES = {
     "mli_engine_get_stats": [_P, ctypes.POINTER(EngineStats)],
     "mli_engine_decoder_result": [_P, _PP, _IP],
     "mli_engine_get_finished": [_P, _I, _IP, _P, _I, _IP],
+    "mli_engine_set_lean_layers": [_I],
     "mli_engine_last_error": [],
 }
 _RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_decoder_scratch_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
-             "mli_engine_destroy": None}
+             "mli_engine_destroy": None, "mli_engine_set_lean_layers": None}
 
 
 def _declare(lib):

@@ -34,6 +34,10 @@ int launch_latest_paged_bf16(uint16_t* const*, const int*, const uint16_t*, cons
                              int, int, hipStream_t);
 int launch_fill_paged_bf16(uint16_t* const*, const int*, const int*, const uint16_t*, const uint16_t*, int, int, int,
                            int, hipStream_t);
+int launch_fill_paged_embed(const float*, const float*, const int*, float* const*, const int*, const int*, const float*,
+                            const float*, int, int, int, int, hipStream_t);
+int launch_fill_paged_bf16_embed(const float*, const float*, const int*, uint16_t* const*, const int*, const int*,
+                                 const uint16_t*, const uint16_t*, int, int, int, int, hipStream_t);
 int launch_qkt_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, hipStream_t);
 int launch_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, void*, size_t,
                                 hipStream_t);
@@ -98,6 +102,21 @@ int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const f
     if (rc) return rc;
     return mli_decoder_fused(attention_result, emb_table, wpe_table, inp_embedding, lengths, decoder_result, n_batch,
                              n_vocab, n_sequence, emb_dim, decoder_scratch, decoder_scratch_bytes, stream);
+}
+
+int mli_paged_prefill(const float* emb_table, const float* wpe, const int* inp, void* const* page_table,
+                      const int* lengths, const int* new_item_indices, const void* wk, const void* wv, int n_batch,
+                      int n_sequence, int emb_dim, int n_new_items, int elem_bf16, void* stream) {
+    if (emb_table == nullptr || wpe == nullptr || inp == nullptr) return MLI_ERR_BAD_ARG;
+    hipStream_t st = mli::as_stream(stream);
+    if (elem_bf16)
+        return mli::launch_fill_paged_bf16_embed(emb_table, wpe, inp, reinterpret_cast<mli_bf16* const*>(page_table),
+                                                 new_item_indices, lengths, static_cast<const mli_bf16*>(wk),
+                                                 static_cast<const mli_bf16*>(wv), n_batch, n_sequence, emb_dim,
+                                                 n_new_items, st);
+    return mli::launch_fill_paged_embed(emb_table, wpe, inp, reinterpret_cast<float* const*>(page_table), new_item_indices,
+                                        lengths, static_cast<const float*>(wk), static_cast<const float*>(wv), n_batch,
+                                        n_sequence, emb_dim, n_new_items, st);
 }
 
 int mli_graph_begin_capture(void* stream) {

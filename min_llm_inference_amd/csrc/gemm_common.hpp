@@ -40,6 +40,12 @@ struct GemmArgs {
     // kPlain only: when set, C is NOT stored; every workgroup reduces its tile to one (max, lowest index of the max)
     // pair per row and writes it to row_best[m * tiles_n + tile] -- the decoder's argmax as the logits GEMM's epilogue
     struct RowBest* row_best;
+    // fill modes only: when emb_table is set, the A rows are not READ from the input-embedding segment but computed
+    // on the fly as emb_table[inp[b, s]] + wpe[s] -- the encoder as the GEMM's prologue -- and the
+    // workgroups of the first column tile also WRITE them there (the decode projection reads position L - 1 later)
+    const float* emb_table;  // [n_vocab, K]
+    const float* wpe;        // [S, K]
+    const int* inp;          // [B, S] token ids
 };
 
 struct RowBest {
@@ -136,6 +142,8 @@ __device__ __forceinline__ void fill_index_lookup(const FI& fi, int n_new, int i
 struct RowDesc {
     const float* a;  // nullptr -> row contributes zeros and is not stored
     float* o;        // BF16 kernels: both point at 16-bit elements and are reinterpreted at the access site
+    const float* e;  // embedding prologue (fill modes, g.emb_table set): emb_table row of the token, fp32
+    const float* p;  //                                                   wpe row of the position, fp32
 };
 
 // bf16 <-> fp32 (bf16 = the upper half of an fp32; products of two bf16 are exact in fp32)
@@ -154,7 +162,7 @@ __device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive 
 
 template <int MODE, bool BF16>
 __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
-    RowDesc r{nullptr, nullptr};
+    RowDesc r{nullptr, nullptr, nullptr, nullptr};
     if (MODE == kPlain) {
         if (m < g.M) {
             r.a = g.a_plain + (int64_t)m * g.lda;
@@ -174,6 +182,10 @@ __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, 
         b = g.new_batch_idx[z];
         s = m;
         if (s >= g.lengths[b] || s >= g.S) return r;
+    }
+    if ((MODE == kNaiveFill || MODE == kPagedFill) && g.emb_table != nullptr) {
+        r.e = g.emb_table + (int64_t)g.inp[(int64_t)b * g.S + s] * g.K;
+        r.p = g.wpe + (int64_t)s * g.K;
     }
     if (MODE == kNaiveLatest || MODE == kNaiveFill) {
         r.a = g.inp_embedding + ((int64_t)b * g.S + s) * g.K;

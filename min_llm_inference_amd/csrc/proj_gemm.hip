@@ -64,6 +64,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     __shared__ __align__(16) float Bs[BK * LDBX];
     __shared__ const float* a_ptr[BM];
     __shared__ float* o_ptr[BM];
+    constexpr bool kFillMode = MODE == kNaiveFill || MODE == kPagedFill;
+    __shared__ const float* e_ptr[kFillMode ? BM : 1];  // embedding prologue: emb_table / wpe row of every A row
+    __shared__ const float* p_ptr[kFillMode ? BM : 1];
 
     const int tiles_n = (g.N + BN - 1) / BN;
     const int wsel = blockIdx.x / tiles_n;
@@ -87,8 +90,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         }
     }
 
+    const bool embed = kFillMode && !BF16 && g.emb_table != nullptr;
     if (tid < BM) {  // BM <= 128 < 256 threads
-        RowDesc r{nullptr, nullptr};
+        RowDesc r{nullptr, nullptr, nullptr, nullptr};
         if ((kFill || kLatest) && g.compact) {
             if (m0 + tid < fill_total) {
                 int zz, ss;
@@ -100,6 +104,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         }
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
+        if (kFillMode) {
+            e_ptr[tid] = r.e;
+            p_ptr[tid] = r.p;
+        }
     }
     // only the contiguous layout keeps K transposed (kt_cache[b, n, s]): element stride S along n
     constexpr bool kCanTranspose = MODE == kNaiveLatest || MODE == kNaiveFill;
@@ -123,8 +131,15 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     // this thread's source rows, kept in registers: re-reading them from LDS every tile put a wait-for-LDS and a
     // branch per pass into every k step
     const float* a_src[AP];
+    const float* e_src[AP];
+    const float* p_src[AP];
 #pragma unroll
-    for (int p = 0; p < AP; ++p) a_src[p] = a_ptr[a_row + p * 32];
+    for (int p = 0; p < AP; ++p) {
+        a_src[p] = a_ptr[a_row + p * 32];
+        e_src[p] = kFillMode ? e_ptr[a_row + p * 32] : nullptr;
+        p_src[p] = kFillMode ? p_ptr[a_row + p * 32] : nullptr;
+    }
+    const bool writes_x = blockIdx.x == 0;  // first column tile of the first weight: every A element passes once
 
     auto load_slab = [&](int k0, float4 (&a_reg)[AP], float4 (&b_reg)[2]) {
 #pragma unroll
@@ -132,7 +147,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
             const float* ap = a_src[p];
             const int k = k0 + a_kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ap != nullptr) {
+            if (kFillMode && embed && ap != nullptr) {
+                // encoder as prologue: x = emb[tok] + wpe[s], the sum the encoder kernel writes (one fp32 add)
+                if (VEC4) {
+                    if (k < g.K) {
+                        const float4 e4 = *reinterpret_cast<const float4*>(e_src[p] + k);
+                        const float4 p4 = *reinterpret_cast<const float4*>(p_src[p] + k);
+                        v = make_float4(e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w);
+                        if (writes_x) *reinterpret_cast<float4*>(const_cast<float*>(ap) + k) = v;
+                    }
+                } else {
+                    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k + i < g.K) {
+                            t[i] = e_src[p][k + i] + p_src[p][k + i];
+                            if (writes_x) const_cast<float*>(ap)[k + i] = t[i];
+                        }
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            } else if (ap != nullptr) {
                 if (BF16) {
                     if (k < g.K) v = load4_bf16(reinterpret_cast<const uint16_t*>(ap) + k);
                 } else if (VEC4) {
@@ -381,19 +415,29 @@ int launch_latest_naive(const float* inp, const int* lengths, const float* wk, c
     return launch_gemm<kNaiveLatest, false>(g, B, 1, vec4, st);
 }
 
-int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, const float* wk, const float* wv,
-                      float* kt, float* v, int B, int S, int Din, int Dout, int n_new, hipStream_t st) {
+// emb_table != nullptr: the encoder runs as the GEMM's prologue (inp_embedding rows are written, not read)
+int launch_fill_naive_embed(const float* emb_table, const float* wpe, const int* tokens, float* inp, const int* new_idx,
+                            const int* lengths, const float* wk, const float* wv, float* kt, float* v, int B, int S,
+                            int Din, int Dout, int n_new, hipStream_t st) {
     if (n_new == 0) return 0;  // reference …optimized.cu:308-310
     if (n_new < 0 || B <= 0) return MLI_ERR_BAD_ARG;
     GemmArgs g{};
+    g.emb_table = emb_table; g.wpe = wpe; g.inp = tokens;
     g.w[0] = wk; g.w[1] = wv; g.n_out = 2;
     g.out_id[0] = 0; g.out_id[1] = 2;
     g.M = S; g.N = Dout; g.K = Din;
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
     g.n_new = n_new; g.compact = fill_compact(n_new);
-    const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wv);
+    const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wv) &&
+                      (emb_table == nullptr || (aligned16(emb_table) && aligned16(wpe)));
     return launch_gemm<kNaiveFill, false>(g, S, n_new, vec4, st);
+}
+
+int launch_fill_naive(const float* inp, const int* new_idx, const int* lengths, const float* wk, const float* wv,
+                      float* kt, float* v, int B, int S, int Din, int Dout, int n_new, hipStream_t st) {
+    return launch_fill_naive_embed(nullptr, nullptr, nullptr, const_cast<float*>(inp), new_idx, lengths, wk, wv, kt, v, B,
+                                   S, Din, Dout, n_new, st);
 }
 
 int launch_latest_paged(float* const* page_table, const int* lengths, const float* wk, const float* wq,
@@ -410,19 +454,26 @@ int launch_latest_paged(float* const* page_table, const int* lengths, const floa
     return launch_gemm<kPagedLatest, false>(g, B, 1, vec4, st);
 }
 
-int launch_fill_paged(float* const* page_table, const int* new_idx, const int* lengths, const float* wk,
-                      const float* wv, int B, int S, int D, int n_new, hipStream_t st) {
+int launch_fill_paged_embed(const float* emb_table, const float* wpe, const int* tokens, float* const* page_table,
+                            const int* new_idx, const int* lengths, const float* wk, const float* wv, int B, int S, int D,
+                            int n_new, hipStream_t st) {
     if (n_new == 0) return 0;  // reference paged_attention.cu:100-102
     if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 4 != 0) return MLI_ERR_BAD_ARG;
     GemmArgs g{};
+    g.emb_table = emb_table; g.wpe = wpe; g.inp = tokens;
     g.w[0] = wk; g.w[1] = wv; g.n_out = 2;
     g.out_id[0] = 0; g.out_id[1] = 2;
     g.M = S; g.N = D; g.K = D;
     g.page_table = page_table; g.lengths = lengths; g.new_batch_idx = new_idx;
     g.B = B; g.S = S;
     g.n_new = n_new; g.compact = fill_compact(n_new);
-    const bool vec4 = aligned16(wk) && aligned16(wv);
+    const bool vec4 = aligned16(wk) && aligned16(wv) && (emb_table == nullptr || (aligned16(emb_table) && aligned16(wpe)));
     return launch_gemm<kPagedFill, false>(g, S, n_new, vec4, st);
+}
+
+int launch_fill_paged(float* const* page_table, const int* new_idx, const int* lengths, const float* wk,
+                      const float* wv, int B, int S, int D, int n_new, hipStream_t st) {
+    return launch_fill_paged_embed(nullptr, nullptr, nullptr, page_table, new_idx, lengths, wk, wv, B, S, D, n_new, st);
 }
 
 // bf16 tile engine: 1 = native v_mfma_f32_32x32x16_bf16 (proj_gemm_bf16.hip, default), 0 = operands widened to
@@ -544,6 +595,19 @@ int mli_get_latest_k_q_v_paged_bf16(mli_bf16* const* page_table, const int* leng
                                     int n_sequence, int emb_dim, void* stream) {
     return mli::launch_latest_paged_bf16(page_table, lengths, wk, wq, wv, q_output, n_batch, n_sequence, emb_dim,
                                          mli::as_stream(stream));
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float* inp_embedding, const int* lengths,
+                const int* new_item_indices, const float* wk, const float* wv, float* kt_cache, float* v_cache,
+                int n_batch, int n_sequence, int input_dim, int output_dim, int n_new_items, void* stream) {
+    if (emb_table == nullptr || wpe == nullptr || inp == nullptr) return MLI_ERR_BAD_ARG;
+    return mli::launch_fill_naive_embed(emb_table, wpe, inp, inp_embedding, new_item_indices, lengths, wk, wv, kt_cache,
+                                        v_cache, n_batch, n_sequence, input_dim, output_dim, n_new_items,
+                                        mli::as_stream(stream));
 }
 
 }  // extern "C"

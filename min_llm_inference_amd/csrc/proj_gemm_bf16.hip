@@ -50,6 +50,9 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     __shared__ __align__(16) unsigned char Bs[HK * kLdbBytes];
     __shared__ const float* a_ptr[HM];
     __shared__ float* o_ptr[HM];
+    constexpr bool kFillMode = MODE == kPagedFill;
+    __shared__ const float* e_ptr[kFillMode ? HM : 1];  // embedding prologue: fp32 emb_table / wpe row of every A row
+    __shared__ const float* p_ptr[kFillMode ? HM : 1];
 
     const int tiles_n = (g.N + HN - 1) / HN;
     const int wsel = blockIdx.x / tiles_n;
@@ -69,8 +72,9 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     } else if (MODE == kPagedFill && m0 >= g.lengths[g.new_batch_idx[z]]) {
         return;
     }
+    const bool embed = kFillMode && g.emb_table != nullptr;
     if (tid < HM) {
-        RowDesc r{nullptr, nullptr};
+        RowDesc r{nullptr, nullptr, nullptr, nullptr};
         if (g.compact) {
             if (m0 + tid < fill_total) {
                 int zz, ss;
@@ -82,6 +86,10 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
         }
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
+        if (kFillMode) {
+            e_ptr[tid] = r.e;
+            p_ptr[tid] = r.p;
+        }
     }
     __syncthreads();
 
@@ -96,14 +104,37 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     const int b_row = tid >> 3, b_n8 = (tid & 7) * 8;                            // B: 32 k-rows x 8 chunks of 8 n
     uint4 a_reg[AP], b_reg[BP];
     const uint16_t* a_src[AP];
+    const float* e_src[AP];
+    const float* p_src[AP];
 #pragma unroll
-    for (int p = 0; p < AP; ++p) a_src[p] = reinterpret_cast<const uint16_t*>(a_ptr[a_row + p * kARowsPerPass]);
+    for (int p = 0; p < AP; ++p) {
+        a_src[p] = reinterpret_cast<const uint16_t*>(a_ptr[a_row + p * kARowsPerPass]);
+        e_src[p] = kFillMode ? e_ptr[a_row + p * kARowsPerPass] : nullptr;
+        p_src[p] = kFillMode ? p_ptr[a_row + p * kARowsPerPass] : nullptr;
+    }
+    const bool writes_x = blockIdx.x == 0;  // first column tile of the first weight: every A element passes once
 
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             a_reg[p] = make_uint4(0, 0, 0, 0);
-            if (a_src[p] != nullptr && k0 + a_k8 < g.K) a_reg[p] = *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8);
+            if (kFillMode && embed && a_src[p] != nullptr) {
+                // encoder as prologue: x = bf16(emb[tok] + wpe[s]) -- fp32 sum, one rounding, what the bf16 encoder
+                // kernel writes -- fed to the MFMA and, by the first column tile, written to the page's segment 0
+                if (k0 + a_k8 < g.K) {
+                    const float4 e0 = *reinterpret_cast<const float4*>(e_src[p] + k0 + a_k8);
+                    const float4 e1 = *reinterpret_cast<const float4*>(e_src[p] + k0 + a_k8 + 4);
+                    const float4 p0 = *reinterpret_cast<const float4*>(p_src[p] + k0 + a_k8);
+                    const float4 p1 = *reinterpret_cast<const float4*>(p_src[p] + k0 + a_k8 + 4);
+                    uint4 x;
+                    x.x = f32_to_bf16(e0.x + p0.x) | ((uint32_t)f32_to_bf16(e0.y + p0.y) << 16);
+                    x.y = f32_to_bf16(e0.z + p0.z) | ((uint32_t)f32_to_bf16(e0.w + p0.w) << 16);
+                    x.z = f32_to_bf16(e1.x + p1.x) | ((uint32_t)f32_to_bf16(e1.y + p1.y) << 16);
+                    x.w = f32_to_bf16(e1.z + p1.z) | ((uint32_t)f32_to_bf16(e1.w + p1.w) << 16);
+                    a_reg[p] = x;
+                    if (writes_x) *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a_src[p]) + k0 + a_k8) = x;
+                }
+            } else if (a_src[p] != nullptr && k0 + a_k8 < g.K) a_reg[p] = *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8);
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
@@ -203,10 +234,13 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     return launch_status();
 }
 
-int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_idx, const int* lengths,
-                                  const uint16_t* wk, const uint16_t* wv, int B, int S, int D, int n_new,
-                                  hipStream_t st) {
+int launch_fill_paged_bf16_embed(const float* emb_table, const float* wpe, const int* tokens,
+                                 uint16_t* const* page_table, const int* new_idx, const int* lengths, const uint16_t* wk,
+                                 const uint16_t* wv, int B, int S, int D, int n_new, hipStream_t st) {
+    if (n_new == 0) return 0;
+    if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 8 != 0) return MLI_ERR_BAD_ARG;
     GemmArgs g{};
+    g.emb_table = emb_table; g.wpe = wpe; g.inp = tokens;
     g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wv); g.n_out = 2;
     g.out_id[0] = 0; g.out_id[1] = 2;
     g.M = S; g.N = D; g.K = D;
@@ -217,6 +251,12 @@ int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_id
     if (g.compact) grid = dim3(ceil_div_i(D, HN) * 2, ceil_div_i(S * n_new, HM), 1);
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedFill>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();
+}
+
+int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_idx, const int* lengths,
+                                  const uint16_t* wk, const uint16_t* wv, int B, int S, int D, int n_new,
+                                  hipStream_t st) {
+    return launch_fill_paged_bf16_embed(nullptr, nullptr, nullptr, page_table, new_idx, lengths, wk, wv, B, S, D, n_new, st);
 }
 
 }  // namespace mli

@@ -43,6 +43,10 @@ public:
                             size_t n_sequence);
     void forward(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_batch_idx,
                  TensorFloat& attention_result, int n_new_items);
+    // encoder + K/V prefill of the new rows in one launch (mli_paged_prefill, elem_bf16 = 1)
+    void prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                 TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_item_indices,
+                 int n_new_items);
 
 private:
     TensorBf16 wk_, wq_, wv_;

@@ -36,6 +36,12 @@ void paged_attention_lean(TensorFloatPoint& page_table, const TensorInt& lengths
                           TensorFloat& q_output, TensorFloat& qkt_output, TensorFloat& attention_result,
                           int n_new_items, int n_sequence);
 
+// EXTENSION: launch_paged_attention_encoder_kernel + launch_fill_new_k_v_cache_paged_attention in one
+// launch -- the embedding lookup is the fill GEMM's prologue; pages bit-identical to the two-launch form.
+void launch_paged_prefill(const TensorFloat& emb_table, const TensorFloat& wpe, const TensorInt& inp,
+                          TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_item_indices,
+                          const TensorFloat& wk, const TensorFloat& wv, int n_new_items);
+
 // "cuBLAS" variants: same results, produced by the same gather-GEMM-scatter MFMA kernel.  latest_emb and
 // temp_placeholder were scratch for the three cublasSgemm calls and are accepted but not used.
 void paged_attention_with_cublas(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,

@@ -7,6 +7,7 @@
 // v_cache [n_batch, n_sequence, output_dim]; q_output [n_batch, output_dim]; qkt_output [n_batch, n_sequence];
 // attention_result [n_batch, output_dim].
 #pragma once
+// (extension at the end of this header: launch_prefill = encoder + launch_fill_new_kt_v_cache in one launch)
 
 #include "tensor.hpp"
 
@@ -30,3 +31,10 @@ void inference_self_attention(const TensorFloat& inp_embedding, const TensorInt&
                               const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
                               TensorFloat& kt_cache, TensorFloat& v_cache, TensorFloat& q_output,
                               TensorFloat& qkt_output, TensorFloat& attention_result, int n_new_items);
+
+// EXTENSION: launch_inference_optimized_encoder_kernel + launch_fill_new_kt_v_cache in one launch --
+// the embedding lookup is the fill GEMM's prologue; inp_embedding, kt_cache and v_cache bit-identical to the two launches.
+void launch_prefill(const TensorFloat& emb_table, const TensorFloat& wpe, const TensorInt& inp,
+                    TensorFloat& inp_embedding, const TensorInt& lengths, const TensorInt& new_item_indices,
+                    const TensorFloat& wk, const TensorFloat& wv, TensorFloat& kt_cache, TensorFloat& v_cache,
+                    int n_new_items);

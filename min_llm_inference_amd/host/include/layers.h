@@ -13,6 +13,9 @@ public:
                        size_t n_sequence);
     void forward(const TensorFloat& inp_embedding, const TensorInt& lengths, const TensorInt& new_batch_idx,
                  TensorFloat& attention_result, int n_new_items);
+    // extension: encoder + K/V prefill of the new rows in one launch (the model then calls forward with n_new_items = 0)
+    void prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                 TensorFloat& inp_embedding, const TensorInt& lengths, const TensorInt& new_item_indices, int n_new_items);
 
 private:
     TensorFloat wk_, wq_, wv_;
@@ -28,6 +31,10 @@ public:
                         size_t n_sequence);
     void forward(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_batch_idx,
                  TensorFloat& attention_result, int n_new_items);
+    // extension: encoder + K/V prefill of the new rows in one launch (the model then calls forward with n_new_items = 0)
+    void prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                 TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_item_indices,
+                 int n_new_items);
 
 private:
     TensorFloat wk_, wq_, wv_;
@@ -41,6 +48,9 @@ public:
                               size_t n_sequence);
     void forward(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_batch_idx,
                  TensorFloat& attention_result, int n_new_items, GemmHandle& handle);
+    void prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                 TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_item_indices,
+                 int n_new_items);  // extension, as PagedAttentionLayer::prefill
 
 private:
     TensorFloat wk_, wq_, wv_;

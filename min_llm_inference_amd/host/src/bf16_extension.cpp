@@ -91,6 +91,16 @@ void PagedAttentionBf16Layer::forward(TensorFloatPoint& page_table, const Tensor
                          n_new_items, n_sequence);
 }
 
+void PagedAttentionBf16Layer::prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                                      TensorFloatPoint& page_table, const TensorInt& lengths,
+                                      const TensorInt& new_item_indices, int n_new_items) {
+    if (n_new_items == 0) return;
+    HIP_CHECK(mli_paged_prefill(emb_table.data(), pos_emb.data(), inp.data(),
+                                reinterpret_cast<void* const*>(page_table.data()), lengths.data(), new_item_indices.data(),
+                                wk_.data(), wv_.data(), (int)inp.shape()[0], (int)inp.shape()[1],
+                                (int)emb_table.shape()[1], n_new_items, /*elem_bf16=*/1, mli::runtime::compute_stream()));
+}
+
 PagedAttentionBf16InferenceModel::PagedAttentionBf16InferenceModel(PagedAttentionBf16Layer&& attention_layer,
                                                                    size_t n_batch, size_t n_sequence, size_t emb_dim,
                                                                    size_t n_vocab, int n_forward_rounds)
@@ -104,10 +114,15 @@ void PagedAttentionBf16InferenceModel::forward(const TensorInt& inp, TensorInt& 
                                                const TensorFloat& pos_emb_table, TensorFloatPoint& page_table) {
     for (int round = 0; round < n_forward_rounds_; ++round) {
         const int fresh = round == 0 ? n_new_items : 0;  // later rounds only decode
-        launch_paged_attention_encoder_kernel_bf16(emb_table.data(), pos_emb_table.data(), inp.data(),
-                                                   page_table.data(), lengths.data(), new_item_indices.data(),
-                                                   (int)n_batch_, (int)n_sequence_, (int)emb_dim_, fresh);
-        attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+        if (mli::runtime::lean_layers()) {
+            attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+            attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0);
+        } else {
+            launch_paged_attention_encoder_kernel_bf16(emb_table.data(), pos_emb_table.data(), inp.data(),
+                                                       page_table.data(), lengths.data(), new_item_indices.data(),
+                                                       (int)n_batch_, (int)n_sequence_, (int)emb_dim_, fresh);
+            attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+        }
         if (mli::runtime::lean_layers()) {
             HIP_CHECK(mli_paged_decoder_fused(attention_result_.data(), emb_table.data(), pos_emb_table.data(),
                                               reinterpret_cast<void* const*>(page_table.data()), lengths.data(),

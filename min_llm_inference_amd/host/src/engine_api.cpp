@@ -236,6 +236,8 @@ struct mli_engine {
 
 extern "C" {
 
+void mli_engine_set_lean_layers(int enabled) { mli::runtime::set_lean_layers(enabled != 0); }
+
 const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
 
 int mli_engine_create(const mli_engine_config* c, const float* emb_table, const float* pos_table, const float* wk,

@@ -2,6 +2,8 @@
 
 #include <utility>
 
+#include "runtime.h"
+
 InferenceModel::InferenceModel(SelfAttentionLayer&& attention_layer, EncoderLayer&& encoder_layer,
                                DecoderLayer&& decoder_layer, size_t n_batch, size_t n_sequence, size_t emb_dim)
     : attention_layer_(std::move(attention_layer)), encoder_layer_(std::move(encoder_layer)),
@@ -12,8 +14,15 @@ InferenceModel::InferenceModel(SelfAttentionLayer&& attention_layer, EncoderLaye
 void InferenceModel::forward(const TensorInt& inp, TensorInt& lengths, const TensorInt& new_item_indices,
                              TensorInt& decoder_result, int n_new_items, const TensorFloat& emb_table,
                              const TensorFloat& pos_emb_table) {
-    encoder_layer_.forward(emb_table, pos_emb_table, inp, inp_embedding_, lengths, new_item_indices, n_new_items);
-    attention_layer_.forward(inp_embedding_, lengths, new_item_indices, attention_result_, n_new_items);
+    if (mli::runtime::lean_layers()) {
+        // encoder + prefill of the new rows in one launch (the embedding lookup is the fill GEMM's prologue), then a pure
+        // decode step; same inp_embedding / caches as the two launches below
+        attention_layer_.prefill(emb_table, pos_emb_table, inp, inp_embedding_, lengths, new_item_indices, n_new_items);
+        attention_layer_.forward(inp_embedding_, lengths, new_item_indices, attention_result_, 0);
+    } else {
+        encoder_layer_.forward(emb_table, pos_emb_table, inp, inp_embedding_, lengths, new_item_indices, n_new_items);
+        attention_layer_.forward(inp_embedding_, lengths, new_item_indices, attention_result_, n_new_items);
+    }
     decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, inp_embedding_, lengths, decoder_result);
 }
 
@@ -32,8 +41,13 @@ void PagedAttentionInferenceModel::forward(const TensorInt& inp, TensorInt& leng
                                            const TensorFloat& pos_emb_table, TensorFloatPoint& page_table) {
     for (int round = 0; round < n_forward_rounds_; ++round) {
         const int fresh = round == 0 ? n_new_items : 0;  // later rounds only decode
-        paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-        paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+        if (mli::runtime::lean_layers()) {
+            paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0);
+        } else {
+            paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+        }
         paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
                                      decoder_result, round);
     }
@@ -54,8 +68,13 @@ void PagedAttentionCublasInferenceModel::forward(const TensorInt& inp, TensorInt
                                                  GemmHandle handle) {
     for (int round = 0; round < n_forward_rounds_; ++round) {
         const int fresh = round == 0 ? n_new_items : 0;
-        paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-        paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh, handle);
+        if (mli::runtime::lean_layers()) {
+            paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0, handle);
+        } else {
+            paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh, handle);
+        }
         paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
                                      decoder_result, round, handle);
     }

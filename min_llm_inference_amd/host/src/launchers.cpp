@@ -175,6 +175,26 @@ void paged_attention(TensorFloatPoint& page_table, const TensorInt& lengths, con
                                   B, n_sequence, D, n_new_items, ws.ptr, ws.bytes, stream()));
 }
 
+void launch_paged_prefill(const TensorFloat& emb_table, const TensorFloat& wpe, const TensorInt& inp,
+                          TensorFloatPoint& page_table, const TensorInt& lengths, const TensorInt& new_item_indices,
+                          const TensorFloat& wk, const TensorFloat& wv, int n_new_items) {
+    if (n_new_items == 0) return;
+    HIP_CHECK(mli_paged_prefill(emb_table.data(), wpe.data(), inp.data(), reinterpret_cast<void* const*>(pages(page_table)),
+                                lengths.data(), new_item_indices.data(), wk.data(), wv.data(), (int)inp.shape()[0],
+                                (int)inp.shape()[1], (int)emb_table.shape()[1], n_new_items, /*elem_bf16=*/0, stream()));
+}
+
+void launch_prefill(const TensorFloat& emb_table, const TensorFloat& wpe, const TensorInt& inp,
+                    TensorFloat& inp_embedding, const TensorInt& lengths, const TensorInt& new_item_indices,
+                    const TensorFloat& wk, const TensorFloat& wv, TensorFloat& kt_cache, TensorFloat& v_cache,
+                    int n_new_items) {
+    if (n_new_items == 0) return;
+    const auto& s = inp_embedding.shape();
+    HIP_CHECK(mli_prefill(emb_table.data(), wpe.data(), inp.data(), inp_embedding.data(), lengths.data(),
+                          new_item_indices.data(), wk.data(), wv.data(), kt_cache.data(), v_cache.data(), (int)s[0],
+                          (int)s[1], (int)s[2], (int)wk.shape()[1], n_new_items, stream()));
+}
+
 // EXTENSION: the composition without the scores (include/mli_kernels.h: mli_paged_attention_lean).  Rows too wide for
 // the single-pass kernel take the materialising composition into the caller's qkt_output scratch instead.
 void paged_attention_lean(TensorFloatPoint& page_table, const TensorInt& lengths, const TensorFloat& wk,

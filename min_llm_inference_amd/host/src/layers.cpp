@@ -28,6 +28,13 @@ void SelfAttentionLayer::forward(const TensorFloat& inp_embedding, const TensorI
                              qkt_output_, attention_result, n_new_items);
 }
 
+void SelfAttentionLayer::prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                                 TensorFloat& inp_embedding, const TensorInt& lengths,
+                                 const TensorInt& new_item_indices, int n_new_items) {
+    launch_prefill(emb_table, pos_emb, inp, inp_embedding, lengths, new_item_indices, wk_, wv_, kt_cache_, v_cache_,
+                   n_new_items);
+}
+
 PagedAttentionLayer::PagedAttentionLayer(TensorFloat&& wk, TensorFloat&& wq, TensorFloat&& wv, size_t n_batch,
                                          size_t emb_dim, size_t n_sequence)
     : wk_(std::move(wk)), wq_(std::move(wq)), wv_(std::move(wv)),
@@ -43,6 +50,18 @@ void PagedAttentionLayer::forward(TensorFloatPoint& page_table, const TensorInt&
     else
         paged_attention(page_table, lengths, wk_, wq_, wv_, new_batch_idx, q_output_, qkt_output_, attention_result,
                         n_new_items, n_sequence);
+}
+
+void PagedAttentionLayer::prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                                  TensorFloatPoint& page_table, const TensorInt& lengths,
+                                  const TensorInt& new_item_indices, int n_new_items) {
+    launch_paged_prefill(emb_table, pos_emb, inp, page_table, lengths, new_item_indices, wk_, wv_, n_new_items);
+}
+
+void PagedAttentionCublasLayer::prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,
+                                        TensorFloatPoint& page_table, const TensorInt& lengths,
+                                        const TensorInt& new_item_indices, int n_new_items) {
+    launch_paged_prefill(emb_table, pos_emb, inp, page_table, lengths, new_item_indices, wk_, wv_, n_new_items);
 }
 
 PagedAttentionCublasLayer::PagedAttentionCublasLayer(TensorFloat&& wk, TensorFloat&& wq, TensorFloat&& wv,

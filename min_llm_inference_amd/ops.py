@@ -232,6 +232,22 @@ def paged_attention_lean(page_table, lengths, wk, wq, wv, new_batch_idx, q_outpu
                                                    _stream()), "mli_paged_attention_lean")
 
 
+def paged_prefill(emb_table, wpe, inp, page_table, lengths, new_item_indices, wk, wv, n_new_items):
+    """Encoder + prefill fill in one launch (mli_paged_prefill); element type from the weights' dtype."""
+    B, S = inp.shape
+    _check(load_library().mli_paged_prefill(_p(emb_table), _p(wpe), _p(inp), _p(page_table), _p(lengths),
+                                            _p(new_item_indices), _p(wk), _p(wv), B, S, emb_table.shape[1], n_new_items,
+                                            int(wk.dtype == torch.bfloat16), _stream()), "mli_paged_prefill")
+
+
+def prefill(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices, wk, wv, kt_cache, v_cache, n_new_items):
+    """Encoder + prefill fill in one launch, contiguous layout (mli_prefill)."""
+    B, S, Din = inp_embedding.shape
+    _check(load_library().mli_prefill(_p(emb_table), _p(wpe), _p(inp), _p(inp_embedding), _p(lengths),
+                                      _p(new_item_indices), _p(wk), _p(wv), _p(kt_cache), _p(v_cache), B, S, Din,
+                                      wk.shape[1], n_new_items, _stream()), "mli_prefill")
+
+
 _decoder_scratch = {}
 
 

@@ -334,3 +334,79 @@ def test_panel_logits_and_argmax_equal_the_tiled_kernel(oracle, mli, dev, seed, 
     oracle.decoder_host(att, emb, score, wpe, inp_emb.copy(), L, res)
     assert_equal(out[2][0], res, what="tokens vs oracle")
     assert_close(out[2][3], score, what="emb_score vs oracle")
+
+
+# ---- prefill: the encoder as the fill GEMM's prologue -------------------------------------------
+def _prefill_inputs(rng, B, S, D, V):
+    emb, wpe = rand_f(rng, (V, D)), rand_f(rng, (S, D))
+    inp = rand_i(rng, (B, S), V - 1)
+    lengths = rand_i(rng, (B,), S - 1)
+    lengths[:4] = [0, 1, S - 1, 17]
+    n_new = int(rng.integers(1, B + 1))
+    new_idx = np.zeros((B,), np.int32)
+    new_idx[:n_new] = rng.permutation(B)[:n_new]
+    w = [((rng.random((D, D), dtype=np.float32) * 2 - 1) / np.sqrt(D)).astype(np.float32) for _ in range(2)]
+    return emb, wpe, inp, lengths, n_new, new_idx, w
+
+
+@pytest.mark.parametrize("compact", [1, 0])
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("seed,B,S,D,V", [(181, 40, 256, 136, 1500), (182, 9, 1024, 512, 1024), (183, 64, 128, 2048, 1024)])
+def test_paged_prefill_equals_encoder_then_fill(mli, dev, seed, B, S, D, V, bf16, compact):
+    """mli_paged_prefill == mli_paged_attention_encoder + mli_fill_new_k_v_cache_paged on the whole page pool, bit for
+    bit (segment 0 written once, K / V from the same fp32 resp. bf16-rounded rows), rows that are not new untouched."""
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    emb, wpe, inp, lengths, n_new, new_idx, w = _prefill_inputs(rng, B, S, D, V)
+    pool, table = build_page_pool(rng, lengths, S, D)
+    esz = 2 if bf16 else 4
+
+    def state():
+        p = _t(bf16_bits(pool).view(np.int16), dev).view(torch.bfloat16) if bf16 else _t(pool, dev)
+        return p, _t(np.where(table >= 0, p.data_ptr() + esz * table, 0).astype(np.int64), dev)
+
+    ws = [(_t(bf16_bits(x).view(np.int16), dev).view(torch.bfloat16) if bf16 else _t(x, dev)) for x in w]
+    args = (_t(emb, dev), _t(wpe, dev), _t(inp, dev))
+    L, idx = _t(lengths, dev), _t(new_idx, dev)
+    assert mli.mli_tune(b"fill_compact", compact) == 0
+    try:
+        p1, t1 = state()
+        ops.paged_prefill(*args, t1, L, idx, ws[0], ws[1], n_new)
+        p2, t2 = state()
+        if bf16:
+            ops.launch_paged_attention_encoder_kernel_bf16(*args, t2, L, idx, n_new)
+            ops.launch_fill_new_k_v_cache_paged_attention_bf16(t2, idx, L, ws[0], ws[1], n_new, S)
+        else:
+            ops.launch_paged_attention_encoder_kernel(*args, t2, L, idx, n_new)
+            ops.launch_fill_new_k_v_cache_paged_attention(t2, idx, L, ws[0], ws[1], n_new, S)
+        torch.cuda.synchronize()
+    finally:
+        mli.mli_tune(b"fill_compact", 1)
+    view = torch.int16 if bf16 else torch.int32
+    assert torch.equal(p1.view(view), p2.view(view)), "page pool: one launch == encoder + fill"
+    changed = (p2.view(view) != (_t(bf16_bits(pool).view(np.int16), dev) if bf16 else _t(pool, dev).view(view))).sum().item()
+    assert changed > 0
+
+
+@pytest.mark.parametrize("seed,B,S,D,V", [(184, 37, 260, 132, 1500), (185, 12, 512, 256, 1024)])
+def test_prefill_contiguous_equals_encoder_then_fill(oracle, mli, dev, seed, B, S, D, V):
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    emb, wpe, inp, lengths, n_new, new_idx, w = _prefill_inputs(rng, B, S, D, V)
+    x0, kt0, v0 = rand_f(rng, (B, S, D)), rand_f(rng, (B, D, S)), rand_f(rng, (B, S, D))
+    args = (_t(emb, dev), _t(wpe, dev), _t(inp, dev))
+    L, idx, wk, wv = _t(lengths, dev), _t(new_idx, dev), _t(w[0], dev), _t(w[1], dev)
+    x1, kt1, v1 = _t(x0, dev), _t(kt0, dev), _t(v0, dev)
+    ops.prefill(*args, x1, L, idx, wk, wv, kt1, v1, n_new)
+    x2, kt2, v2 = _t(x0, dev), _t(kt0, dev), _t(v0, dev)
+    ops.launch_inference_optimized_encoder_kernel(*args, x2, L, idx, n_new)
+    ops.launch_fill_new_kt_v_cache(x2, idx, L, wk, wv, kt2, v2, n_new)
+    assert_equal(host(x1), host(x2), what="inp_embedding")
+    assert_equal(host(kt1), host(kt2), what="kt_cache")
+    assert_equal(host(v1), host(v2), what="v_cache")
+    # and the oracle's two host functions
+    oracle.inference_optimized_encoder_host(emb, wpe, inp, x0, lengths, new_idx, n_new)
+    oracle.fill_new_kt_v_cache(x0, new_idx, lengths, w[0], w[1], kt0, v0, n_new)
+    assert_close(host(x1), x0, thr=0, what="inp_embedding vs oracle")
+    assert_close(host(kt1), kt0, what="kt_cache vs oracle")
+    assert_close(host(v1), v0, what="v_cache vs oracle")
