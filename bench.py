@@ -426,8 +426,8 @@ def run_engine_mode(args, rank, world, dev):
                        reference_length_reset_quirk=args.reference_quirk)
         if R > 1:
             e.use_private_stream()
-        if args.pipelined:
-            e.set_pipelined()
+        if args.pipelined or args.sequential_loop:
+            e.set_pipelined(not args.sequential_loop)   # default: the engine picks the pipelined loop where it applies
         for i, toks in items[r::R]:
             e.add_item(i, toks)
         engines.append(e)
@@ -502,7 +502,10 @@ def main():
     ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16"], default="paged_gemm",
                     help="paged_bf16 = extension: bf16 pages and weights (BASELINE config 4 dtype)")
     ap.add_argument("--pipelined", action="store_true",
-                    help="engine mode: the pipelined loop (host one step behind the GPU; per-slot device updates)")
+                    help="engine mode: insist on the pipelined loop (host one step behind the GPU; per-slot device "
+                         "updates) -- it is the default wherever it applies")
+    ap.add_argument("--sequential-loop", action="store_true",
+                    help="engine mode: the reference's sequential loop order (forward, result, pages, insert)")
     ap.add_argument("--engine-replicas", type=int, default=1,
                     help="engine mode: split the slots over this many engines on the same GPU (private streams, one "
                          "host thread each) so one engine's host bookkeeping overlaps the other's kernels")
@@ -581,7 +584,7 @@ def main():
                 "config": {"workload": ("engine: reference tests/paged_for_profile.cpp workload" if ref_shape else
                                         f"engine: {args.workload} shape under the reference's profiling recipe") +
                                        f" (B={eB} slots, S={eS}, D={eD}, V={eV}, {e_blocks} pages, {2 * eB} items, "
-                                       f"prompt U[1,64]), {args.engine_kind} engine x{args.engine_replicas}{' pipelined' if args.pipelined else ''}, ThroughputCounter tokens/s incl. "
+                                       f"prompt U[1,64]), {args.engine_kind} engine x{args.engine_replicas}, {'sequential' if args.sequential_loop or args.reference_quirk else 'pipelined'} loop, ThroughputCounter tokens/s incl. "
                                        "host scheduling, prefill, page growth and preemption",
                            "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
                            "reference_length_reset_quirk": bool(args.reference_quirk),
@@ -689,8 +692,9 @@ def engine_config(args, dev):
     in a child process so that the engine's allocations and host threads never share this process's timed region."""
     import subprocess
     out = {}
-    for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_pipelined", ["--pipelined"]),
-                         ("e1_f32_paged_gemm_reference_launch_sequence", ["--reference-launch-sequence"])):
+    for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_sequential_loop", ["--sequential-loop"]),
+                         ("e1_f32_paged_gemm_sequential_loop_reference_launch_sequence",
+                          ["--sequential-loop", "--reference-launch-sequence"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "engine", "--gpus", "1", *extra]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

@@ -57,11 +57,13 @@ void mli_engine_destroy(mli_engine* engine);
  * thread at a time. */
 int mli_engine_use_private_stream(mli_engine* engine);
 
-/* EXTENSION: make mli_engine_run use the pipelined loop of the paged kinds -- the host works one
- * step behind the GPU (page growth and admission for step k+1 while step k's result is still in flight; per-slot
- * device updates instead of whole-tensor uploads), min_llm_inference_amd/host/include/pipelined_engine.h.  Per-item
- * token streams are identical to the sequential loop's.  n_forward_rounds must be 1; call before the first run;
- * mli_engine_step is not available on a pipelined engine. */
+/* EXTENSION: the pipelined loop of the paged kinds -- the host works one step behind the GPU (page
+ * growth and admission for step k+1 while step k's result is still in flight; per-slot device updates instead of
+ * whole-tensor uploads), min_llm_inference_amd/host/include/pipelined_engine.h.  Per-item token streams are identical
+ * to the sequential loop's.  It is what mli_engine_run uses BY DEFAULT wherever it applies: a paged kind,
+ * n_forward_rounds <= 8, no reference_length_reset_quirk, an engine that has not been stepped.  enabled = 0 selects
+ * the reference's sequential loop order, enabled = 1 insists on the pipelined loop (mli_engine_run then fails where it
+ * does not apply, and mli_engine_step is refused).  Call before the first run. */
 int mli_engine_set_pipelined(mli_engine* engine, int enabled);
 
 /* Queue one item (ItemStorage::add_new_item). */

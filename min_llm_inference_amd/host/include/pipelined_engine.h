@@ -15,7 +15,7 @@
 // Differences an observer can see: a freed slot is refilled one iteration later (its result is known one iteration
 // later), and a row preempted while its token is in flight has that token dropped and regenerated after
 // re-admission.  Per-item token streams are identical to the sequential engines' (greedy decoding is per row;
-// tests/test_engine_gpu.py).  n_forward_rounds = 1 only (what every driver of the reference runs).
+// tests/test_engine_gpu.py).  n_forward_rounds up to PAGE_BLOCK_SIZE / 2: a row then has up to R tokens in flight.
 #pragma once
 
 #include <functional>
@@ -30,23 +30,23 @@ using PagedForward = std::function<void(const TensorInt&, TensorInt&, const Tens
 long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorage& processing_storage,
                                      MemoryBlockManager& memory_block_manager,
                                      PagedAttentionsManager& paged_attention_manager, size_t n_batch_size,
-                                     size_t n_sequence, const PagedForward& forward);
+                                     size_t n_sequence, const PagedForward& forward, int n_forward_rounds = 1);
 
 void start_paged_attention_inference_engine_pipelined(const TensorFloat& emb_table, const TensorFloat& pos_table,
                                                       ItemStorage& item_storage, ProcessingStorage& processing_storage,
                                                       MemoryBlockManager& memory_block_manager,
                                                       PagedAttentionsManager& paged_attention_manager,
                                                       PagedAttentionInferenceModel& inference_model,
-                                                      size_t n_batch_size, size_t n_sequence);
+                                                      size_t n_batch_size, size_t n_sequence, int n_forward_rounds = 1);
 
 void start_paged_attention_cublas_inference_engine_pipelined(
     const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
     ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
     PagedAttentionsManager& paged_attention_manager, PagedAttentionCublasInferenceModel& inference_model,
-    size_t n_batch_size, size_t n_sequence);
+    size_t n_batch_size, size_t n_sequence, int n_forward_rounds = 1);
 
 void start_paged_attention_bf16_inference_engine_pipelined(
     const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
     ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
     PagedAttentionsManager& paged_attention_manager, PagedAttentionBf16InferenceModel& inference_model,
-    size_t n_batch_size, size_t n_sequence);
+    size_t n_batch_size, size_t n_sequence, int n_forward_rounds = 1);

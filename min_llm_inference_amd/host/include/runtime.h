@@ -33,6 +33,13 @@ void release_attention_scratch(void* stream) noexcept;  // frees the buffers tie
 void set_lean_layers(bool enabled);
 bool lean_layers();
 
+// Which loop start_paged_attention_*_inference_engine runs (process-wide; default false): the pipelined loop
+// (pipelined_engine.h: the host one step behind the GPU, same tokens per item) wherever it applies -- up to
+// PAGE_BLOCK_SIZE / 2 forward rounds, no length-reset quirk --, or, with true, always the reference's sequential order
+// forward -> process_decoder_result -> allocate_or_free_memory_blocks_if_needed -> insert_new_items.
+void set_sequential_engine_loop(bool enabled);
+bool sequential_engine_loop();
+
 // roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
 void range_push(const char* name);
 void range_pop();

@@ -51,7 +51,15 @@ struct mli_engine {
     long long iterations = 0;
     GemmHandle handle;
     ThroughputCounter counter;  // this engine's own (the reference has one per process)
-    bool pipelined = false;     // mli_engine_set_pipelined: run() uses the pipelined loop (pipelined_engine.h)
+    int pipelined = -1;         // mli_engine_set_pipelined: 1 / 0 = run() uses the pipelined / the sequential loop,
+                                // -1 (default) = pipelined wherever it applies (see use_pipelined())
+    // the pipelined loop serves the paged kinds with up to PAGE_BLOCK_SIZE / 2 rounds, without the reference's quirk,
+    // and only an engine that is run to completion from the start (mli_engine_step drives the sequential loop)
+    bool pipelined_applies() const {
+        return cfg.kind != MLI_ENGINE_CONTIGUOUS && 2 * cfg.n_forward_rounds <= PAGE_BLOCK_SIZE &&
+               !cfg.reference_length_reset_quirk && !started;
+    }
+    bool use_pipelined() const { return pipelined == 1 || (pipelined == -1 && pipelined_applies()); }
     void* stream = nullptr;     // private compute stream (mli_engine_use_private_stream), else the thread's
 
     ~mli_engine() {
@@ -155,8 +163,8 @@ struct mli_engine {
 
     void run_pipelined() {
         if (started) throw std::runtime_error("pipelined run on an engine that has already been stepped");
-        if (!paged() || cfg.n_forward_rounds != 1)
-            throw std::runtime_error("the pipelined loop serves the paged kinds with n_forward_rounds = 1");
+        if (!paged() || 2 * cfg.n_forward_rounds > PAGE_BLOCK_SIZE)
+            throw std::runtime_error("the pipelined loop serves the paged kinds with n_forward_rounds <= PAGE_BLOCK_SIZE / 2");
         pages->set_length_reset_quirk(cfg.reference_length_reset_quirk != 0);
         get_global_throughput_counter().reset();
         started = true;
@@ -172,7 +180,7 @@ struct mli_engine {
                 else
                     gemm_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
                                         pages->get_page_table_device(), handle);
-            });
+            }, cfg.n_forward_rounds);
     }
 
     double t_forward = 0, t_result = 0, t_pages = 0, t_insert = 0;  // host seconds per phase (MLI_ENGINE_TIMING=1)
@@ -258,7 +266,7 @@ int mli_engine_create(const mli_engine_config* c, const float* emb_table, const 
 }
 
 void mli_engine_destroy(mli_engine* e) {
-    if (e && std::getenv("MLI_ENGINE_TIMING") && e->iterations && !e->pipelined)
+    if (e && std::getenv("MLI_ENGINE_TIMING") && e->iterations && e->t_forward > 0)
         std::fprintf(stderr, "[mli engine] %lld iterations; host us/iteration: launch forward %.1f, wait + process "
                      "decoder result %.1f, page bookkeeping %.1f, insert + uploads %.1f\n", e->iterations,
                      1e6 * e->t_forward / e->iterations, 1e6 * e->t_result / e->iterations,
@@ -281,13 +289,13 @@ int mli_engine_use_private_stream(mli_engine* e) {
 int mli_engine_set_pipelined(mli_engine* e, int enabled) {
     MLI_GUARD({
         if (e->started) throw std::runtime_error("set_pipelined after the engine has started");
-        e->pipelined = enabled != 0;
+        e->pipelined = enabled != 0 ? 1 : 0;
     })
 }
 
 int mli_engine_step(mli_engine* e, int* done) {
     MLI_GUARD({
-        if (e->pipelined) throw std::runtime_error("a pipelined engine is run to completion (mli_engine_run)");
+        if (e->pipelined == 1) throw std::runtime_error("a pipelined engine is run to completion (mli_engine_run)");
         mli_engine::Scope scope(e);
         e->step();
         if (done) *done = e->done() ? 1 : 0;
@@ -297,7 +305,7 @@ int mli_engine_step(mli_engine* e, int* done) {
 int mli_engine_run(mli_engine* e, mli_engine_stats* stats) {
     MLI_GUARD({
         mli_engine::Scope scope(e);
-        if (e->pipelined) {
+        if (e->use_pipelined()) {
             e->run_pipelined();
         } else {
             if (!e->started) e->start();

@@ -6,6 +6,8 @@
 #include <vector>
 
 #include "bf16_extension.h"
+#include "constants.h"
+#include "pipelined_engine.h"
 #include "runtime.h"
 #include "throughput_counter.h"
 
@@ -89,6 +91,12 @@ void run_paged_engine(ItemStorage& item_storage, ProcessingStorage& processing_s
     get_global_throughput_counter().print_throughput();
 }
 
+
+// the pipelined loop is the default wherever it applies (runtime.h: set_sequential_engine_loop)
+bool pipelined_loop_applies(const PagedAttentionsManager& pages, int n_forward_rounds) {
+    return !mli::runtime::sequential_engine_loop() && 2 * n_forward_rounds <= PAGE_BLOCK_SIZE && !pages.length_reset_quirk();
+}
+
 }  // namespace
 
 void start_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
@@ -117,6 +125,12 @@ void start_paged_attention_inference_engine(const TensorFloat& emb_table, const 
                                             PagedAttentionsManager& paged_attention_manager,
                                             PagedAttentionInferenceModel& inference_model, size_t n_batch_size,
                                             size_t n_sequence, int n_forward_rounds) {
+    if (pipelined_loop_applies(paged_attention_manager, n_forward_rounds)) {
+        start_paged_attention_inference_engine_pipelined(emb_table, pos_table, item_storage, processing_storage,
+                                                         memory_block_manager, paged_attention_manager, inference_model,
+                                                         n_batch_size, n_sequence, n_forward_rounds);
+        return;
+    }
     run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
                      n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
                          inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
@@ -131,6 +145,12 @@ void start_paged_attention_cublas_inference_engine(const TensorFloat& emb_table,
                                                    PagedAttentionsManager& paged_attention_manager,
                                                    PagedAttentionCublasInferenceModel& inference_model,
                                                    size_t n_batch_size, size_t n_sequence, int n_forward_rounds) {
+    if (pipelined_loop_applies(paged_attention_manager, n_forward_rounds)) {
+        start_paged_attention_cublas_inference_engine_pipelined(emb_table, pos_table, item_storage, processing_storage,
+                                                                memory_block_manager, paged_attention_manager,
+                                                                inference_model, n_batch_size, n_sequence, n_forward_rounds);
+        return;
+    }
     GemmHandle handle;  // the reference creates / destroys a cublasHandle_t here; nothing to create for MFMA
     run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
                      n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
@@ -147,6 +167,12 @@ void start_paged_attention_bf16_inference_engine(const TensorFloat& emb_table, c
                                                  PagedAttentionsManager& paged_attention_manager,
                                                  PagedAttentionBf16InferenceModel& inference_model,
                                                  size_t n_batch_size, size_t n_sequence, int n_forward_rounds) {
+    if (pipelined_loop_applies(paged_attention_manager, n_forward_rounds)) {
+        start_paged_attention_bf16_inference_engine_pipelined(emb_table, pos_table, item_storage, processing_storage,
+                                                              memory_block_manager, paged_attention_manager,
+                                                              inference_model, n_batch_size, n_sequence, n_forward_rounds);
+        return;
+    }
     run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
                      n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
                          inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,

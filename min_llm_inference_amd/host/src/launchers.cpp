@@ -47,7 +47,10 @@ mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequenc
 
 namespace {
 bool g_lean_layers = true;
+bool g_sequential_engine_loop = false;
 }
+void mli::runtime::set_sequential_engine_loop(bool enabled) { g_sequential_engine_loop = enabled; }
+bool mli::runtime::sequential_engine_loop() { return g_sequential_engine_loop; }
 void mli::runtime::set_lean_layers(bool enabled) { g_lean_layers = enabled; }
 bool mli::runtime::lean_layers() { return g_lean_layers; }
 

@@ -28,7 +28,12 @@ struct MarkerHandle {
 
 long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorage& processing_storage,
                                      MemoryBlockManager& pool, PagedAttentionsManager& pages, size_t n_batch_size,
-                                     size_t n_sequence, const PagedForward& forward) {
+                                     size_t n_sequence, const PagedForward& forward, int n_forward_rounds) {
+    // Every in-flight row has up to R tokens in flight and is about to produce R more, so the page bookkeeping is asked
+    // for tokens + 2 R positions; its rule "a row needs at most one more page per pass" holds while 2 R <= PAGE_BLOCK_SIZE.
+    const int R = n_forward_rounds;
+    if (R < 1 || 2 * R > PAGE_BLOCK_SIZE)
+        throw std::runtime_error("the pipelined engine serves 1 <= n_forward_rounds <= PAGE_BLOCK_SIZE / 2");
     if (pages.length_reset_quirk())
         throw std::runtime_error("the pipelined engine does not reproduce the reference's length-reset quirk");
     const int B = static_cast<int>(n_batch_size), S = static_cast<int>(n_sequence);
@@ -38,7 +43,8 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
     // staging for the new-row indices of forward(k) is reused for forward(k+2): by then the marker of step k+1,
     // recorded after forward(k+1) was queued, has been waited for, so the copy that fed forward(k) has executed
     TensorInt new_idx_host[2] = {TensorInt({n_batch_size}, DeviceType::HOST), TensorInt({n_batch_size}, DeviceType::HOST)};
-    TensorInt result_device({n_batch_size, 1}, DeviceType::DEVICE), result_host({n_batch_size, 1}, DeviceType::HOST);
+    const size_t n_rounds = static_cast<size_t>(R);
+    TensorInt result_device({n_batch_size, n_rounds}, DeviceType::DEVICE), result_host({n_batch_size, n_rounds}, DeviceType::HOST);
     MarkerHandle marker;
 
     // first_step[b] = index of the first forward this occupant of slot b takes part in; -1 = slot empty
@@ -56,7 +62,7 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
         TensorInt& staging = new_idx_host[step & 1];
         const bool nothing_in_flight = processing_storage.size() == 0;  // then every slot and every page is free
         PagedAdmission adm = admit_new_items(inp_host.data(), lengths_host.data(), staging.data(), B, S, item_storage,
-                                             processing_storage, pool, pages, /*n_forward_rounds=*/1);
+                                             processing_storage, pool, pages, R);
         if (nothing_in_flight && adm.slots.empty() && item_storage.new_count() > 0) {
             // the whole pool cannot hold the head item: an error, not the endless loop of the reference's engine
             mli::runtime::synchronize();
@@ -97,16 +103,17 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
     }
     while (true) {
         // A. result(step) starts travelling as soon as forward(step) is done
-        result_host.copy_range_from_async(result_device, 0, n_batch_size);
+        result_host.copy_range_from_async(result_device, 0, n_batch_size * n_rounds);
         mli::mem::record_marker(marker.m);
 
-        // B. pages for forward(step + 1): every in-flight row has exactly one token in flight, so it needs room for
-        //    tokens + 2 positions (the reference's rule with the in-flight token counted); a dry pool preempts from
-        //    the tail of the admission list, and the victim's device length is zeroed before forward(step + 1)
+        // B. pages for forward(step + 1): every in-flight row has up to R tokens in flight (one per round of
+        //    forward(step)) and forward(step + 1) appends up to R more, so it needs room for tokens + 2 R positions
+        //    (the reference's rule with the in-flight tokens counted); a dry pool preempts from the tail of the
+        //    admission list, and the victim's device length is zeroed before forward(step + 1)
         {
             Range r("allocate_or_free_memory_blocks_if_needed");
             const size_t in_flight_before = processing_storage.size();
-            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2);
+            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2 * R);
             if (in_flight_before > 0 && processing_storage.size() == 0) {
                 // Every row was preempted, the last one by itself: with the whole pool to itself it still has no room
                 // for its next token.  Re-admitting it (its in-flight token is dropped, so it would fit again) and
@@ -144,24 +151,27 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
             int appended = 0;
             for (int b = 0; b < B; ++b) {
                 if (first_step[b] < 0 || first_step[b] > step) continue;  // empty, or admitted after forward(step)
-                const int tok = tokens[b];
-                if (tok == EMPTY_ROW_TOKEN_ID) throw std::runtime_error("pipelined engine: in-flight row reported empty");
                 IdTokensPair& item = processing_storage.get_token(b);
-                append_token_to_id_string_pair(item, tok);
-                ++appended;
-                if (tok == EOF_TOKEN_ID || static_cast<int>(item.second.size()) >= S) {
-                    processing_storage.move_to_finished(b, item_storage);
-                    first_step[b] = -1;
-                    lengths_host.data()[b] = 0;  // the decoder zeroed the device length already
-                    finished.push_back(b);
+                for (int r = 0; r < R; ++r) {  // one token per round until the row finishes (later rounds: EMPTY)
+                    const int tok = tokens[static_cast<size_t>(b) * R + r];
+                    if (tok == EMPTY_ROW_TOKEN_ID) throw std::runtime_error("pipelined engine: in-flight row reported empty");
+                    append_token_to_id_string_pair(item, tok);
+                    ++appended;
+                    if (tok == EOF_TOKEN_ID || static_cast<int>(item.second.size()) >= S) {
+                        processing_storage.move_to_finished(b, item_storage);
+                        first_step[b] = -1;
+                        lengths_host.data()[b] = 0;  // the decoder zeroed the device length already
+                        finished.push_back(b);
+                        break;
+                    }
                 }
             }
             get_global_throughput_counter().add_record_if_recording(appended);
         }
-        // pages of finished rows go back; with rounds = 1 and the tokens just appended this asks for exactly what B
+        // pages of finished rows go back; with R rounds and the tokens just appended this asks for no more than B
         // already provided, so nothing grows here
         if (!finished.empty())
-            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/1);
+            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/R);
         ++step;
         if (is_done(item_storage, processing_storage)) break;
 

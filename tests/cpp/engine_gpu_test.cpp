@@ -86,6 +86,7 @@ int main() {
     std::map<int, std::vector<int>> paged_reference_sequence;
     {
         mli::runtime::set_lean_layers(false);
+        mli::runtime::set_sequential_engine_loop(true);   // ... and in the reference's loop order
         ItemStorage storage;
         ProcessingStorage processing;
         for (const auto& it : items) storage.add_new_item(IdTokensPair(it));
@@ -95,7 +96,8 @@ int main() {
                                            PagedDecoderLayer(B, V), B, S, D, 1);
         start_paged_attention_inference_engine(emb, pos, storage, processing, pool, pages, model, B, S, 1);
         mli::runtime::set_lean_layers(true);
-        std::printf("paged engine, materialising layers: finished %d of %d\n", storage.finish_count(), n_items);
+        mli::runtime::set_sequential_engine_loop(false);
+        std::printf("paged engine, sequential loop, materialising layers: finished %d of %d\n", storage.finish_count(), n_items);
         failures += storage.finish_count() != n_items;
         paged_reference_sequence = collect(storage);
     }
@@ -184,6 +186,7 @@ int main() {
         PagedAttentionInferenceModel model(PagedAttentionLayer(clone(wk), clone(wq), clone(wv), 2, D, S), PagedEncoderLayer(),
                                            PagedDecoderLayer(2, V), 2, S, D, 1);
         bool threw = false;
+        mli::runtime::set_sequential_engine_loop(scenario != 2);
         try {
             if (scenario == 2)
                 start_paged_attention_inference_engine_pipelined(emb_no_eof, pos, storage, processing, pool, pages, model, 2, S);
@@ -192,6 +195,7 @@ int main() {
         } catch (const std::runtime_error& e) {
             threw = std::strstr(e.what(), "too small") != nullptr;
         }
+        mli::runtime::set_sequential_engine_loop(false);
         std::printf("pool of %d pages, %s loop: %s\n", n_blocks, scenario == 2 ? "pipelined" : "sequential",
                     threw ? "reported as too small" : "NOT reported");
         failures += !threw;

@@ -32,6 +32,7 @@ struct FakeModel {
     PagedAttentionsManager* pages;
     long long launches = 0;
     int missing_pages = 0;
+    int rounds = 1;   // decode rounds per forward: result is [B, rounds], a finished row reports EMPTY in later rounds
 
     static uint64_t mix(uint64_t h, uint64_t x) {
         h ^= x + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
@@ -56,19 +57,21 @@ struct FakeModel {
             for (int s = 0; s < len[b]; ++s) hh = mix(hh, static_cast<uint64_t>(in[b * S + s]));
             h[b] = hh;
         }
-        for (int b = 0; b < B; ++b) {
-            const int L = len[b];
-            if (L <= 0) {
-                res[b] = EMPTY_ROW_TOKEN_ID;
-                continue;
+        for (int r = 0; r < rounds; ++r) {
+            for (int b = 0; b < B; ++b) {
+                const int L = len[b];
+                if (L <= 0) {
+                    res[b * rounds + r] = EMPTY_ROW_TOKEN_ID;
+                    continue;
+                }
+                for (int s = 0; s <= L && s < S; s += PAGE_BLOCK_SIZE)   // pages of positions 0 .. L (L = next write)
+                    if (table[b * width + s / PAGE_BLOCK_SIZE] == nullptr) ++missing_pages;
+                if (L < S && table[b * width + L / PAGE_BLOCK_SIZE] == nullptr) ++missing_pages;
+                const int tok = token_of(h[b]);
+                res[b * rounds + r] = tok;
+                h[b] = mix(h[b], static_cast<uint64_t>(tok));
+                len[b] = (tok == EOF_TOKEN_ID || L + 1 >= S) ? 0 : L + 1;
             }
-            for (int s = 0; s <= L && s < S; s += PAGE_BLOCK_SIZE)   // pages of positions 0 .. L (L = next write)
-                if (table[b * width + s / PAGE_BLOCK_SIZE] == nullptr) ++missing_pages;
-            if (L < S && table[b * width + L / PAGE_BLOCK_SIZE] == nullptr) ++missing_pages;
-            const int tok = token_of(h[b]);
-            res[b] = tok;
-            h[b] = mix(h[b], static_cast<uint64_t>(tok));
-            len[b] = (tok == EOF_TOKEN_ID || L + 1 >= S) ? 0 : L + 1;
         }
     }
 };
@@ -91,25 +94,26 @@ static std::map<int, std::vector<int>> collect(const ItemStorage& s) {
 }
 
 // the reference's loop order (src/inferencer.cpp:43-122) from the scheduler primitives
-static long long run_sequential(World& w, FakeModel& model, size_t B, size_t S) {
+static long long run_sequential(World& w, FakeModel& model, size_t B, size_t S, int R = 1) {
     TensorInt inp_d({B, S}, DeviceType::DEVICE), inp_h({B, S}, DeviceType::HOST);
     TensorInt len_d({B}, DeviceType::DEVICE), len_h({B}, DeviceType::HOST);
     TensorInt idx_d({B}, DeviceType::DEVICE), idx_h({B}, DeviceType::HOST);
-    TensorInt res_d({B, 1}, DeviceType::DEVICE), res_h({B, 1}, DeviceType::HOST);
+    TensorInt res_d({B, (size_t)R}, DeviceType::DEVICE), res_h({B, (size_t)R}, DeviceType::HOST);
     for (size_t b = 0; b < B; ++b) len_h.data()[b] = len_d.data()[b] = 0;
-    std::vector<int> fresh = insert_new_items(inp_d, inp_h, len_d, len_h, idx_d, idx_h, w.items, w.processing, w.pool, w.pages, 1);
+    std::vector<int> fresh = insert_new_items(inp_d, inp_h, len_d, len_h, idx_d, idx_h, w.items, w.processing, w.pool, w.pages, R);
     long long steps = 0;
     while (!is_done(w.items, w.processing)) {
         model.forward(inp_d, len_d, idx_d, res_d, static_cast<int>(fresh.size()));
         std::vector<int> finished = process_decoder_result(res_d, res_h, w.items, w.processing, static_cast<int>(S));
-        allocate_or_free_memory_blocks_if_needed(w.pages, w.pool, w.processing, w.items, finished, 1);
-        fresh = insert_new_items(inp_d, inp_h, len_d, len_h, idx_d, idx_h, w.items, w.processing, w.pool, w.pages, 1);
+        allocate_or_free_memory_blocks_if_needed(w.pages, w.pool, w.processing, w.items, finished, R);
+        fresh = insert_new_items(inp_d, inp_h, len_d, len_h, idx_d, idx_h, w.items, w.processing, w.pool, w.pages, R);
         if (++steps > 1000000) break;
     }
     return steps;
 }
 
-static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_items, int max_prompt, int eof_bias) {
+static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_items, int max_prompt, int eof_bias,
+                     int rounds = 1) {
     std::mt19937 rng(seed);
     std::vector<IdTokensPair> items;
     for (int i = 0; i < n_items; ++i) {
@@ -124,9 +128,10 @@ static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_item
         World w(B, S, n_blocks);
         for (const auto& it : items) w.items.add_new_item(IdTokensPair(it));
         FakeModel model{(int)B, (int)S, eof_bias, std::vector<uint64_t>(B, 0), &w.pages};
+        model.rounds = rounds;
         get_global_throughput_counter().reset();
         get_global_throughput_counter().start_record();
-        run_sequential(w, model, B, S);
+        run_sequential(w, model, B, S, rounds);
         appended_seq = get_global_throughput_counter().total_tokens();
         seq = collect(w.items);
         missing_seq = model.missing_pages;
@@ -136,11 +141,12 @@ static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_item
         World w(B, S, n_blocks);
         for (const auto& it : items) w.items.add_new_item(IdTokensPair(it));
         FakeModel model{(int)B, (int)S, eof_bias, std::vector<uint64_t>(B, 0), &w.pages};
+        model.rounds = rounds;
         get_global_throughput_counter().reset();
         run_paged_engine_pipelined(w.items, w.processing, w.pool, w.pages, B, S,
                                    [&](const TensorInt& inp, TensorInt& len, const TensorInt& idx, TensorInt& res, int n_new) {
                                        model.forward(inp, len, idx, res, n_new);
-                                   });
+                                   }, rounds);
         appended_pip = get_global_throughput_counter().total_tokens();
         pip = collect(w.items);
         missing_pip = model.missing_pages;
@@ -155,8 +161,8 @@ static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_item
     int different = 0;
     for (const auto& kv : seq) different += pip[kv.first] != kv.second;
     CHECK(different == 0);
-    std::printf("%s seed %u: B=%zu S=%zu blocks=%d items=%d eof=%d%%  tokens %lld  (items differing: %d)\n",
-                different == 0 && missing_pip == 0 ? "[ OK ]" : "[FAIL]", seed, B, S, n_blocks, n_items, eof_bias,
+    std::printf("%s seed %u: B=%zu S=%zu blocks=%d items=%d eof=%d%% rounds=%d  tokens %lld  (items differing: %d)\n",
+                different == 0 && missing_pip == 0 ? "[ OK ]" : "[FAIL]", seed, B, S, n_blocks, n_items, eof_bias, rounds,
                 appended_pip, different);
 }
 
@@ -171,6 +177,19 @@ int main() {
         const int max_prompt = 1 + rng() % (S - 2);
         const int eof_bias = (seed % 3 == 0) ? 0 : static_cast<int>(rng() % 12);
         run_case(1000 + seed, B, S, n_blocks, n_items, max_prompt, eof_bias);
+    }
+    // several decode rounds per forward: up to R tokens of a row in flight, rows finishing in the middle of a forward,
+    // preemption dropping up to R generated tokens at once
+    for (unsigned seed = 0; seed < 30; ++seed) {
+        const size_t B = 1 + rng() % 24;
+        const size_t S = 16 * (2 + rng() % 9);
+        const int width = static_cast<int>(S / 16);
+        const int n_blocks = std::max<int>(width + DEFAULT_INIT_NUM_BLOCKS, (1 + rng() % 8) * static_cast<int>(B));
+        const int n_items = 1 + rng() % (3 * B + 3);
+        const int rounds = 2 + rng() % 7;   // 2 .. 8
+        const int max_prompt = 1 + rng() % (S - 2 - rounds);
+        const int eof_bias = (seed % 3 == 0) ? 0 : static_cast<int>(rng() % 12);
+        run_case(2000 + seed, B, S, n_blocks, n_items, max_prompt, eof_bias, rounds);
     }
     {   // a pool that cannot hold even one row: an error, not an endless loop
         World w(4, 64, DEFAULT_INIT_NUM_BLOCKS - 1);

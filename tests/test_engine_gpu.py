@@ -19,8 +19,8 @@ def _run(kind, model, items, B, S, n_blocks=0, rounds=1, quirk=False, pipelined=
     V = model["emb_table"].shape[0]
     e = eng.Engine(kind, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
                    n_blocks=n_blocks, n_forward_rounds=rounds, reference_length_reset_quirk=quirk)
-    if pipelined:
-        e.set_pipelined()
+    if kind != eng.CONTIGUOUS:
+        e.set_pipelined(bool(pipelined))   # explicit either way: the default picks the pipelined loop where it applies
     for item_id, toks in items:
         e.add_item(item_id, toks)
     st = e.run()
@@ -211,6 +211,76 @@ def test_pipelined_engine_random_configurations(mli, dev, seed):
     assert st_seq.total_tokens == st_pip.total_tokens
     for item_id, _ in items:
         assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), (item_id, B, S, D, n_blocks)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pipelined_engine_multi_round_random_configurations(oracle, mli, dev, seed):
+    """n_forward_rounds > 1 in the pipelined loop (up to R tokens of a row in flight, rows finishing in the middle of a
+    forward, preemption dropping up to R generated tokens): same tokens per item as the sequential multi-round loop,
+    as the one-round engine, and as the CPU engine."""
+    from min_llm_inference_amd import engine as eng
+    from engine_sim import run_cpu_engine
+    rng = np.random.default_rng(5000 + seed)
+    B = int(rng.integers(2, 32))
+    S = 16 * int(rng.integers(3, 11))
+    D = 4 * int(rng.integers(4, 40))
+    V = 1024 + int(rng.integers(0, 300))
+    rounds = int(rng.integers(2, 9))
+    n_items = int(rng.integers(1, 3 * B + 2))
+    max_prompt = max(1, min(S - 2 - rounds, int(rng.integers(1, S))))
+    n_blocks = max(S // 16 + 4, int(rng.integers(2, 8)) * B)
+    kind = [eng.PAGED, eng.PAGED_GEMM][seed % 2]
+    model = make_model(6000 + seed, V, S, D)
+    items = make_items(7000 + seed, n_items, 1, max_prompt)
+    st_seq, seq = _run(kind, model, items, B, S, n_blocks=n_blocks, rounds=rounds)
+    st_pip, pip = _run(kind, model, items, B, S, n_blocks=n_blocks, rounds=rounds, pipelined=True)
+    st_one, one = _run(kind, model, items, B, S, n_blocks=n_blocks, rounds=1, pipelined=True)
+    cpu, _ = run_cpu_engine(oracle, model, items, B, S)
+    assert st_seq.finished == n_items and st_pip.finished == n_items, (B, S, D, n_items, n_blocks, rounds)
+    for item_id, _ in items:
+        for name, got in (("sequential", seq), ("pipelined", pip), ("one round", one)):
+            assert len(got[item_id]) == len(cpu[item_id]) and (got[item_id] == cpu[item_id]).all(), \
+                (name, item_id, B, S, D, n_blocks, rounds)
+
+
+def test_default_engine_loop_is_the_pipelined_one_where_it_applies(mli, dev):
+    """mli_engine_run without mli_engine_set_pipelined: the pipelined loop for a paged engine (fewer iterations are not
+    a criterion -- the same number of forwards --, so the check is that stepping is still possible only on an engine
+    that was never run, and that tokens equal the explicit sequential run); the quirk keeps the sequential loop."""
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 24, 128, 64, 1024
+    model = make_model(91, V, S, D)
+    items = make_items(92, 2 * B + 3, 1, 40)
+    _, seq = _run(eng.PAGED, model, items, B, S, n_blocks=4 * B, pipelined=False)
+    e = eng.Engine(eng.PAGED, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
+                   n_blocks=4 * B)
+    for item_id, toks in items:
+        e.add_item(item_id, toks)
+    st = e.run()
+    got = {i: t for i, t in e.finished()}
+    e.close()
+    assert st.finished == len(items)
+    for item_id, _ in items:
+        assert (got[item_id] == seq[item_id]).all()
+    st_q, _ = _run(eng.PAGED, model, items, B, S, n_blocks=4 * B, quirk=True)   # _run selects sequential explicitly
+    assert st_q.finished == len(items)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_pool_that_cannot_hold_a_rows_growth_is_an_error_not_a_hang(mli, dev, pipelined):
+    """a pool that admits a row (>= 4 pages) but cannot hold its growth, no EOF.  The sequential loop ends in
+    'pool too small'; the pipelined loop used to preempt / re-admit the row forever."""
+    from min_llm_inference_amd import MliError, engine as eng
+    B, S, D, V = 2, 160, 64, 1024
+    model = make_model(58, V, S, D)
+    model["emb_table"][1023] = 0.0   # EOF never wins the argmax
+    e = eng.Engine(eng.PAGED, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
+                   n_blocks=5)
+    e.set_pipelined(pipelined)
+    e.add_item(0, np.array([1, 2, 3], np.int32))
+    with pytest.raises(MliError, match="too small"):
+        e.run()
+    e.close()
 
 
 @pytest.mark.parametrize("pipelined", [False, True])
