@@ -403,6 +403,7 @@ def run_engine_mode(args, rank, world, dev):
     replica of the workload on its own GPU."""
     from min_llm_inference_amd import engine as eng
     ops.load_library().mli_engine_set_lean_layers(0 if args.reference_launch_sequence else 1)
+    ops.load_library().mli_engine_set_step_graphs(1 if args.step_graphs else 0)
     _, B, D, S = WORKLOADS[args.workload if args.workload != "c4" or args.engine_shape else "e1"]
     V = N_VOCAB
     rng = np.random.default_rng(0x5EED0100 + rank)
@@ -424,7 +425,7 @@ def run_engine_mode(args, rank, world, dev):
     for r in range(R):  # R engines of B / R slots each share the GPU (private streams, one host thread each)
         e = eng.Engine(kind, B // R, S, D, V, *weights, n_blocks=n_blocks // R, n_forward_rounds=1, device=dev.index,
                        reference_length_reset_quirk=args.reference_quirk)
-        if R > 1:
+        if R > 1 or args.step_graphs:
             e.use_private_stream()
         if args.pipelined or args.sequential_loop:
             e.set_pipelined(not args.sequential_loop)   # default: the engine picks the pipelined loop where it applies
@@ -504,6 +505,8 @@ def main():
     ap.add_argument("--pipelined", action="store_true",
                     help="engine mode: insist on the pipelined loop (host one step behind the GPU; per-slot device "
                          "updates) -- it is the default wherever it applies")
+    ap.add_argument("--step-graphs", action="store_true",
+                    help="engine mode: private stream + decode forwards replayed from a hipGraph (one host call each)")
     ap.add_argument("--sequential-loop", action="store_true",
                     help="engine mode: the reference's sequential loop order (forward, result, pages, insert)")
     ap.add_argument("--engine-replicas", type=int, default=1,

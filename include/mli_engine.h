@@ -91,6 +91,12 @@ int mli_engine_get_finished(mli_engine* engine, int index, int* id, int* tokens,
  * identical either way; the switch exists to measure one against the other. */
 void mli_engine_set_lean_layers(int enabled);
 
+/* Process-wide: 1 = the models replay their pure decode forwards (no newly inserted rows) from a hipGraph recorded on
+ * the first such forward -- one host call per forward instead of one per launch (host/include/step_graph.h).  Only
+ * engines with a private stream can record (the legacy default stream cannot be captured); others keep launching
+ * eagerly.  Default 0: a replay costs the GPU a few microseconds more than the same launches issued from C++. */
+void mli_engine_set_step_graphs(int enabled);
+
 const char* mli_engine_last_error(void);
 
 #ifdef __cplusplus

@@ -109,10 +109,12 @@ ENGINE_SIGNATURES = {
     "mli_engine_decoder_result": [_P, _PP, _IP],
     "mli_engine_get_finished": [_P, _I, _IP, _P, _I, _IP],
     "mli_engine_set_lean_layers": [_I],
+    "mli_engine_set_step_graphs": [_I],
     "mli_engine_last_error": [],
 }
 _RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_decoder_scratch_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
-             "mli_engine_destroy": None, "mli_engine_set_lean_layers": None}
+             "mli_engine_destroy": None, "mli_engine_set_lean_layers": None,
+             "mli_engine_set_step_graphs": None}
 
 
 def _declare(lib):

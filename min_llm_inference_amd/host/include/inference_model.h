@@ -2,6 +2,7 @@
 #pragma once
 
 #include "layers.h"
+#include "step_graph.h"
 #include "tensor.hpp"
 #include "utils.h"
 
@@ -40,6 +41,7 @@ private:
     size_t n_batch_, n_sequence_, emb_dim_;
     TensorFloat attention_result_;
     int n_forward_rounds_;
+    StepGraph decode_graph_;  // replay of the n_new_items == 0 forward (runtime::set_step_graphs)
 };
 
 class PagedAttentionCublasInferenceModel : public NonCopyableNonClonable {
@@ -58,4 +60,5 @@ private:
     size_t n_batch_, n_sequence_, emb_dim_;
     TensorFloat attention_result_;
     int n_forward_rounds_;
+    StepGraph decode_graph_;  // replay of the n_new_items == 0 forward (runtime::set_step_graphs)
 };

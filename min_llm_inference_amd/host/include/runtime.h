@@ -40,6 +40,10 @@ bool lean_layers();
 void set_sequential_engine_loop(bool enabled);
 bool sequential_engine_loop();
 
+// hipGraph replay of decode forwards (step_graph.h); process-wide, default false.
+void set_step_graphs(bool enabled);
+bool step_graphs();
+
 // roctx ranges around engine phases (the reference wraps them in NVTX ranges, src/inferencer.cpp:55-82)
 void range_push(const char* name);
 void range_pop();

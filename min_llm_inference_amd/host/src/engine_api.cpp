@@ -246,6 +246,8 @@ extern "C" {
 
 void mli_engine_set_lean_layers(int enabled) { mli::runtime::set_lean_layers(enabled != 0); }
 
+void mli_engine_set_step_graphs(int enabled) { mli::runtime::set_step_graphs(enabled != 0); }
+
 const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
 
 int mli_engine_create(const mli_engine_config* c, const float* emb_table, const float* pos_table, const float* wk,

@@ -39,18 +39,28 @@ void PagedAttentionInferenceModel::forward(const TensorInt& inp, TensorInt& leng
                                            const TensorInt& new_item_indices, TensorInt& decoder_result,
                                            int n_new_items, const TensorFloat& emb_table,
                                            const TensorFloat& pos_emb_table, TensorFloatPoint& page_table) {
-    for (int round = 0; round < n_forward_rounds_; ++round) {
-        const int fresh = round == 0 ? n_new_items : 0;  // later rounds only decode
-        if (mli::runtime::lean_layers()) {
-            paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0);
-        } else {
-            paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+    auto rounds = [&](int n_new) {
+        for (int round = 0; round < n_forward_rounds_; ++round) {
+            const int fresh = round == 0 ? n_new : 0;  // later rounds only decode
+            if (mli::runtime::lean_layers()) {
+                paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+                paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0);
+            } else {
+                paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+                paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh);
+            }
+            paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
+                                         decoder_result, round);
         }
-        paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
-                                     decoder_result, round);
+    };
+    if (n_new_items != 0) {
+        rounds(n_new_items);
+        return;
     }
+    // a pure decode forward depends on device state only through these buffers: replayable (step_graph.h)
+    decode_graph_.run({inp.data(), lengths.data(), new_item_indices.data(), decoder_result.data(), emb_table.data(),
+                       pos_emb_table.data(), page_table.data()},
+                      [&] { rounds(0); });
 }
 
 PagedAttentionCublasInferenceModel::PagedAttentionCublasInferenceModel(
@@ -66,16 +76,25 @@ void PagedAttentionCublasInferenceModel::forward(const TensorInt& inp, TensorInt
                                                  int n_new_items, const TensorFloat& emb_table,
                                                  const TensorFloat& pos_emb_table, TensorFloatPoint& page_table,
                                                  GemmHandle handle) {
-    for (int round = 0; round < n_forward_rounds_; ++round) {
-        const int fresh = round == 0 ? n_new_items : 0;
-        if (mli::runtime::lean_layers()) {
-            paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0, handle);
-        } else {
-            paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
-            paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh, handle);
+    auto rounds = [&](int n_new) {
+        for (int round = 0; round < n_forward_rounds_; ++round) {
+            const int fresh = round == 0 ? n_new : 0;
+            if (mli::runtime::lean_layers()) {
+                paged_attention_layer_.prefill(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+                paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, 0, handle);
+            } else {
+                paged_encoder_layer_.forward(emb_table, pos_emb_table, inp, page_table, lengths, new_item_indices, fresh);
+                paged_attention_layer_.forward(page_table, lengths, new_item_indices, attention_result_, fresh, handle);
+            }
+            paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
+                                         decoder_result, round, handle);
         }
-        paged_decoder_layer_.forward(attention_result_, emb_table, pos_emb_table, page_table, lengths,
-                                     decoder_result, round, handle);
+    };
+    if (n_new_items != 0) {
+        rounds(n_new_items);
+        return;
     }
+    decode_graph_.run({inp.data(), lengths.data(), new_item_indices.data(), decoder_result.data(), emb_table.data(),
+                       pos_emb_table.data(), page_table.data()},
+                      [&] { rounds(0); });
 }

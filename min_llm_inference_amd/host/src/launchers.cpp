@@ -14,6 +14,7 @@
 #include "kernels/self_attention_inference_optimized.h"
 #include "mli_kernels.h"
 #include "runtime.h"
+#include "step_graph.h"
 #include "utils.h"
 
 // Split-sequence scratch, one buffer per (device, compute stream) -- kernels of two streams may run at the same
@@ -48,6 +49,51 @@ mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequenc
 namespace {
 bool g_lean_layers = true;
 bool g_sequential_engine_loop = false;
+bool g_step_graphs = false;
+}
+void mli::runtime::set_step_graphs(bool enabled) { g_step_graphs = enabled; }
+bool mli::runtime::step_graphs() { return g_step_graphs; }
+
+StepGraph::~StepGraph() { reset(); }
+StepGraph::StepGraph(StepGraph&& other) noexcept
+    : exec_(other.exec_), key_(std::move(other.key_)), seen_(other.seen_), replayed_(false) {
+    other.exec_ = nullptr;
+    other.seen_ = 0;
+}
+void StepGraph::reset() noexcept {
+    if (exec_) (void)mli_graph_destroy(exec_);
+    exec_ = nullptr;
+    seen_ = 0;
+}
+bool StepGraph::begin(const std::vector<const void*>& key) {
+    replayed_ = false;
+    void* st = mli::runtime::compute_stream();
+    if (!mli::runtime::step_graphs() || st == nullptr) return false;
+    std::vector<const void*> full(key);
+    full.push_back(st);
+    if (full != key_) {
+        reset();
+        key_ = full;
+    }
+    if (exec_ != nullptr) {
+        HIP_CHECK(mli_graph_launch(exec_, st));
+        replayed_ = true;
+        return false;
+    }
+    if (seen_++ == 0) return false;   // first forward over these buffers: eager, scratch gets allocated
+    HIP_CHECK(mli_graph_begin_capture(st));
+    return true;
+}
+void StepGraph::finish() {
+    void* st = mli::runtime::compute_stream();
+    HIP_CHECK(mli_graph_end_capture(st, &exec_));
+    HIP_CHECK(mli_graph_launch(exec_, st));
+}
+void StepGraph::abandon() noexcept {
+    void* discard = nullptr;
+    (void)mli_graph_end_capture(mli::runtime::compute_stream(), &discard);
+    if (discard) (void)mli_graph_destroy(discard);
+    reset();
 }
 void mli::runtime::set_sequential_engine_loop(bool enabled) { g_sequential_engine_loop = enabled; }
 bool mli::runtime::sequential_engine_loop() { return g_sequential_engine_loop; }

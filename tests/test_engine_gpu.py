@@ -243,6 +243,35 @@ def test_pipelined_engine_multi_round_random_configurations(oracle, mli, dev, se
                 (name, item_id, B, S, D, n_blocks, rounds)
 
 
+@pytest.mark.parametrize("kind_name,rounds,pipelined", [("PAGED", 1, True), ("PAGED_GEMM", 3, True), ("PAGED", 2, False)])
+def test_step_graph_replay_gives_the_same_tokens(oracle, mli, dev, kind_name, rounds, pipelined):
+    """Decode forwards replayed from a hipGraph (recorded on the engine's private stream at the second pure decode
+    forward) == the same forwards launched one kernel at a time: tokens per item equal the CPU engine's, with
+    preemption and prefill forwards (eager) in between the replays."""
+    from min_llm_inference_amd import engine as eng
+    from engine_sim import run_cpu_engine
+    B, S, D, V = 24, 160, 128, 1024
+    model = make_model(95, V, S, D)
+    items = make_items(96, 3 * B, 1, 50)
+    cpu, _ = run_cpu_engine(oracle, model, items, B, S)
+    mli.mli_engine_set_step_graphs(1)
+    try:
+        e = eng.Engine(getattr(eng, kind_name), B, S, D, V, model["emb_table"], model["pos_table"], model["wk"],
+                       model["wq"], model["wv"], n_blocks=4 * B, n_forward_rounds=rounds)
+        e.use_private_stream()
+        e.set_pipelined(pipelined)
+        for item_id, toks in items:
+            e.add_item(item_id, toks)
+        st = e.run()
+        got = {i: t for i, t in e.finished()}
+        e.close()
+    finally:
+        mli.mli_engine_set_step_graphs(0)
+    assert st.finished == len(items)
+    for item_id, _ in items:
+        assert len(got[item_id]) == len(cpu[item_id]) and (got[item_id] == cpu[item_id]).all(), item_id
+
+
 def test_default_engine_loop_is_the_pipelined_one_where_it_applies(mli, dev):
     """mli_engine_run without mli_engine_set_pipelined: the pipelined loop for a paged engine (fewer iterations are not
     a criterion -- the same number of forwards --, so the check is that stepping is still possible only on an engine
