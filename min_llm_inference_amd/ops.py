@@ -145,7 +145,28 @@ def paged_attention(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qk
                                               n_new_items, _p(ws), need, _stream()), "mli_paged_attention")
 
 
-paged_attention_with_cublas = paged_attention  # one gather-GEMM-scatter kernel replaces the cuBLAS trio
+class GemmHandle:
+    """Stands where the reference passes a cublasHandle_t (include/kernels/paged_attention.h:46-63); empty."""
+
+
+def launch_get_latest_k_q_v_paged_attention_cublas(page_table, lengths, latest_emb, wk, wq, wv, q_output,
+                                                   temp_placeholder, handle, n_sequence):
+    """The reference's argument list (paged_attention.h:57-63).  latest_emb / temp_placeholder were scratch of the
+    three cublasSgemm calls: accepted, never touched (one gather-GEMM-scatter kernel needs neither)."""
+    assert isinstance(handle, GemmHandle) and latest_emb.shape == q_output.shape == temp_placeholder.shape
+    launch_get_latest_k_q_v_paged_attention(page_table, lengths, wk, wq, wv, q_output, n_sequence)
+
+
+def paged_attention_with_cublas(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qkt_output, attention_result,
+                                latest_emb=None, temp_placeholder=None, n_new_items=None, n_sequence=None, handle=None):
+    """paged_attention.h:46-54 (…, latest_emb, temp_placeholder, n_new_items, n_sequence, handle); the short form
+    (…, attention_result, n_new_items, n_sequence) of paged_attention is accepted too."""
+    if n_sequence is None:  # called with paged_attention's positional list
+        latest_emb, temp_placeholder, n_new_items, n_sequence = None, None, latest_emb, temp_placeholder
+    else:
+        assert isinstance(handle, GemmHandle) and latest_emb.shape == q_output.shape == temp_placeholder.shape
+    paged_attention(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, qkt_output, attention_result,
+                    n_new_items, n_sequence)
 
 
 # ---- bf16 paged path (extension; BASELINE config 4).  page_table addresses point at bf16 pages ----------
@@ -354,7 +375,12 @@ def launch_paged_attention_decoder_multi_rounds(batch_result, emb_table, emb_sco
            "mli_paged_decoder_multi_rounds")
 
 
-launch_paged_attention_cublas_decoder_multi_rounds = launch_paged_attention_decoder_multi_rounds
+def launch_paged_attention_cublas_decoder_multi_rounds(batch_result, emb_table, emb_score, wpe_table, page_table, lengths,
+                                                       decoder_result, i_decoder, handle=None):
+    """decoder.h:32-37: the same head with a cublasHandle_t at the end (a GemmHandle here; nothing to hand to MFMA)."""
+    assert handle is None or isinstance(handle, GemmHandle)
+    launch_paged_attention_decoder_multi_rounds(batch_result, emb_table, emb_score, wpe_table, page_table, lengths,
+                                                decoder_result, i_decoder)
 
 
 # ---- test / measurement support -------------------------------------------------------------

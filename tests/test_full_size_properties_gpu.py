@@ -224,3 +224,48 @@ def test_config3_full_size_step_matches_the_oracle(oracle, mli, dev):
     idx = np.arange(wl.B)
     assert_close(k_after[idx, L - 1], kt[idx, :, L - 1], what="appended K rows")
     assert_close(v_after[idx, L - 1], v[idx, L - 1], what="appended V rows")
+
+
+def test_config2_full_size_step_matches_the_oracle(oracle, mli, dev):
+    """BASELINE config 2 at its full size (B=256, D=256, S=1024, contiguous caches, fp32): one decode step -- the
+    materialising composition and the lean one-call step -- against the oracle on every row; slots at or beyond a row's
+    length are NaN in all three caches and must never reach a result."""
+    from min_llm_inference_amd import ops
+    wl = _workload("c2", dev, "f32")
+    L = wl.lengths_host.copy()
+    s = torch.arange(wl.S, device=wl.dev)
+    dead = s[None, :] >= wl.lengths[:, None]                                    # [B, S]
+    wl.inp_embedding[dead] = float("nan")
+    wl.v_cache[dead] = float("nan")
+    wl.kt_cache.transpose(1, 2)[dead] = float("nan")
+    x = torch.nan_to_num(wl.inp_embedding).cpu().numpy()
+    kt = torch.nan_to_num(wl.kt_cache).cpu().numpy()
+    v = torch.nan_to_num(wl.v_cache).cpu().numpy()
+    kt0, v0 = wl.kt_cache.clone(), wl.v_cache.clone()
+    ops.inference_self_attention(wl.inp_embedding, wl.lengths, wl.wk, wl.wq, wl.wv, wl.new_idx, wl.kt_cache, wl.v_cache,
+                                 wl.q_output, wl.qkt_output, wl.attention_result, 0)
+    torch.cuda.synchronize()
+    _check_probabilities(wl, wl.qkt_output)
+    q = np.zeros((wl.B, wl.D), np.float32)
+    sc = np.zeros((wl.B, wl.S), np.float32)
+    o = np.zeros((wl.B, wl.D), np.float32)
+    w = [t.cpu().numpy() for t in (wl.wk, wl.wq, wl.wv)]
+    oracle.self_attention_inference_host(x, L, w[0], w[1], w[2], np.zeros((wl.B,), np.int32), kt, v, q, sc, o, 0)
+    assert_close(wl.q_output.cpu().numpy(), q, what="q_output")
+    assert_close(wl.qkt_output.cpu().numpy(), sc, what="probabilities")
+    assert_close(wl.attention_result.cpu().numpy(), o, what="attention_result")
+    idx = np.arange(wl.B)
+    assert_close(wl.kt_cache.cpu().numpy()[idx, :, L - 1], kt[idx, :, L - 1], what="appended K columns")
+    assert_close(wl.v_cache.cpu().numpy()[idx, L - 1], v[idx, L - 1], what="appended V rows")
+    # the lean one-call step (what bench.py times) from the same state: same attention_result, then the decoder head
+    first = wl.attention_result.clone()
+    wl.kt_cache.copy_(kt0); wl.v_cache.copy_(v0)
+    wl.attention_result.zero_()
+    wl.lean_step()
+    torch.cuda.synchronize()
+    assert torch.equal(wl.attention_result, first)
+    tok = wl.decoder_result.view(-1).cpu().numpy()
+    logits = o @ wl.emb_table.cpu().numpy().T
+    best = logits.max(axis=1)
+    assert (logits[idx, tok] >= best - 1e-3).all(), "decoder token = an argmax of the oracle's logits (1e-3)"
+    assert (wl.lengths.cpu().numpy() == L + 1).all()
