@@ -324,6 +324,16 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      them, cut into pieces of "scan_tail_tokens" tokens (what is still running when the queue runs
  *                      dry is short), 0 = plain chunk order
  *   "scan_tail_tokens" 0 (default) = the remainder stays one piece, else a power of two in [64, chunk]: piece size
+ *   "scan_stream"      (lean mode) 1 (default) = batches that fill the chip (n_batch * n_sequence >= 2^21, n_batch <= 2048,
+ *                      n_sequence >= 256) are scanned in EQUAL PAGE SHARES: the pages of all rows form one sequence
+ *                      that 2 x CUs workgroups split evenly, each streaming its share across row boundaries and merging
+ *                      per row like "scan_merge" (attention_stream.hip); 0 = always one workgroup per (row, chunk).
+ *                      Same result for the same lengths on every launch; against the chunked form the split points of
+ *                      a row differ, i.e. the fp32 rounding of the merge (<= 1e-5 on attention_result)
+ *   "scan_stream_min_tokens"  the n_batch * n_sequence threshold of "scan_stream" (tests lower it)
+ *   "scan_stream_dynamic_pct" / "scan_stream_granule"  the last x per cent (default 4, at most 12; 0 = none) of the page
+ *                      sequence are not part of the equal shares but handed out by a ticket counter in granules of that
+ *                      many pages (default 64, 16..256) to the workgroups that finish their share first
  *   "scan_merge"       (lean mode) 1 (default) = the workgroup that completes a row merges its chunks inside the scan
  *                      launch, 0 = a separate combine launch; bit-identical results
  *   "scan_dynamic_items" 1 = the single-pass scan hands its (row, chunk) items out through a ticket counter (balances

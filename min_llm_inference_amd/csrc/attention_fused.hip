@@ -13,7 +13,7 @@
 //   combine grid = B, 256 threads
 #include <type_traits>
 
-#include "device_common.hpp"
+#include "scan_common.hpp"
 
 namespace mli {
 
@@ -32,44 +32,13 @@ constexpr int kFuWaves = kFuThreads / kWave;
 
 int sv_chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip
 int tuned_chunk_tokens();
+template <class E>
+int launch_stream_decode(const float* q, const void* const* page_table, const int* lengths, float* out, int B, int S, int D,
+                         void* ws, size_t ws_bytes, hipStream_t st);   // attention_stream.hip
+template <class E>
+bool stream_decode_applies(int B, int S, int D);
 size_t stats_region_bytes_for(int B, int S);
 int nt_loads_enabled();
-
-typedef uint32_t fu_u32x4 __attribute__((ext_vector_type(4)));
-typedef const fu_u32x4 __attribute__((address_space(1)))* fu_gu4_ptr;
-
-template <int N, class F, int I = 0>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, F, I + 1>(static_cast<F&&>(f));
-    }
-}
-
-template <bool NT>
-__device__ __forceinline__ fu_u32x4 fu_ldg(const void* p) {
-    if (NT) return __builtin_nontemporal_load((fu_gu4_ptr)(p));
-    return *(fu_gu4_ptr)(p);
-}
-
-// one 16-byte lane load holds EPL elements
-struct ElemF32 {
-    static constexpr int EPL = 4;
-    static constexpr int kBytes = 4;
-    static __device__ __forceinline__ void unpack(const fu_u32x4& r, float (&f)[4]) {
-        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
-    }
-};
-struct ElemBF16 {
-    static constexpr int EPL = 8;
-    static constexpr int kBytes = 2;
-    static __device__ __forceinline__ void unpack(const fu_u32x4& r, float (&f)[8]) {
-        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
-    }
-};
 
 // number of (m, l, partial) triples a row of length L produces: full chunks + pieces of the remainder
 __host__ __device__ __forceinline__ int row_items(int L, int ct, int tail) {
@@ -570,6 +539,13 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
                                float* out, int B, int S, int D, void* ws, size_t ws_bytes, hipStream_t st,
                                int phases = 3) {
     const bool lean = (phases & 4) != 0;
+    if (lean && g_scan_merge && g_flash) {
+        // chip-filling batches: equal page shares instead of (row, chunk) workgroups (attention_stream.hip); one launch
+        // does the whole job, so the "combine only" phase has nothing left to do
+        const int r = (phases & 1) ? launch_stream_decode<E>(q, page_table, lengths, out, B, S, D, ws, ws_bytes, st)
+                                   : (stream_decode_applies<E>(B, S, D) ? 1 : 0);
+        if (r != 0) return r;
+    }
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
     if (!g_flash || nj > 8 || D % E::EPL != 0 || S % kPage != 0) return 0;

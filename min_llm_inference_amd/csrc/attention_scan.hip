@@ -26,6 +26,10 @@ void set_flash_variant(int v);
 void set_scan_merge(int v);
 void set_gemm_panel(int v);
 void set_tail_tokens(int v);
+void set_scan_stream(int v);
+void set_scan_stream_min(int v);
+void set_stream_dyn_pct(int v);
+void set_stream_granule(int v);
 void set_dynamic_items(int v);
 void set_partial_last(int v);
 void set_gemm_tall_tiles(int v);
@@ -689,6 +693,14 @@ int mli_tune(const char* key, int value) {
         mli::set_gemm_tall_tiles(value);
     } else if (k == "scan_partial_last") {
         mli::set_partial_last(value);
+    } else if (k == "scan_stream") {
+        mli::set_scan_stream(value);
+    } else if (k == "scan_stream_dynamic_pct") {
+        mli::set_stream_dyn_pct(value);
+    } else if (k == "scan_stream_granule") {
+        mli::set_stream_granule(value);
+    } else if (k == "scan_stream_min_tokens") {
+        mli::set_scan_stream_min(value);
     } else if (k == "scan_tail_tokens") {
         if (value != 0 && (value < 64 || value > 1024 || (value & (value - 1)))) return MLI_ERR_BAD_ARG;
         mli::set_tail_tokens(value);

@@ -62,6 +62,69 @@ def test_lean_scan_matches_oracle_and_the_materialising_form(oracle, mli, dev, s
     assert (full[c["lengths"] == 0] == 0).all()
 
 
+# (seed, B, S, D, lengths): long rows shared by many workgroups, short rows (several per workgroup, more than one group),
+# empty rows in between, a single row, exactly-full pages
+STREAM_CASES = [
+    (191, 48, 4096, 512, None),
+    (192, 300, 1024, 128, None),
+    (193, 2048, 1024, 64, "short"),
+    (194, 1, 4096, 256, [4095]),
+    (195, 9, 1024, 1024, [0, 1023, 0, 0, 16, 17, 512, 1, 1008]),
+    (196, 64, 2048, 256, "short"),
+]
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("seed,B,S,D,lengths", STREAM_CASES)
+@pytest.mark.parametrize("dyn", [12, 0])
+def test_lean_scan_equal_page_shares(oracle, mli, dev, seed, B, S, D, lengths, bf16, dyn):
+    """attention_stream.hip forced onto small shapes (its size threshold lowered): every row's result within 1e-5 of the
+    chunked form (other split points), within 1e-3 of the oracle, empty rows zero, and bit-identical from launch to launch
+    (the shares depend on the lengths only; rows merged in token order by whichever workgroup arrives last)."""
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    if isinstance(lengths, str):
+        lengths = rng.integers(0, 70, size=B).astype(np.int32)      # many rows per workgroup share
+    c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, lengths=lengths, zero_every=None if lengths is not None else 7)
+    if bf16:
+        if D % 8:
+            pytest.skip("bf16 rows are multiples of 8")
+        c["pool"] = bf16_round(c["pool"])
+        p16 = _t(bf16_bits(c["pool"]).view(np.int16), dev).view(torch.bfloat16)
+        d["pool16"] = p16
+        d["page_table"] = _t(np.where(c["table"] >= 0, p16.data_ptr() + 2 * c["table"], 0).astype(np.int64), dev)
+    else:
+        pass
+    q = d["q_output"]
+    mli.mli_tune(b"scan_stream", 0)
+    try:
+        ops.decode_scan_paged(q, d["page_table"], d["lengths"], None, d["attention_result"], bf16, phases=7, n_sequence=S)
+        chunked = host(d["attention_result"]).copy()
+        mli.mli_tune(b"scan_stream", 1)
+        assert mli.mli_tune(b"scan_stream_min_tokens", 0) == 0
+        assert mli.mli_tune(b"scan_stream_dynamic_pct", dyn) == 0   # 0: equal static shares only; 12: + granules by ticket
+        assert mli.mli_tune(b"scan_stream_granule", 16) == 0
+        outs = []
+        for _ in range(3):
+            d["attention_result"].fill_(SENTINEL)
+            ops.decode_scan_paged(q, d["page_table"], d["lengths"], None, d["attention_result"], bf16, phases=7, n_sequence=S)
+            outs.append(host(d["attention_result"]).copy())
+    finally:
+        mli.mli_tune(b"scan_stream", 1)
+        mli.mli_tune(b"scan_stream_min_tokens", 1 << 21)
+        mli.mli_tune(b"scan_stream_dynamic_pct", 4)
+        mli.mli_tune(b"scan_stream_granule", 64)
+    assert_equal(outs[1], outs[0], what="second launch")
+    assert_equal(outs[2], outs[0], what="third launch")
+    assert_close(outs[0], chunked, thr=1e-5, what="equal shares vs chunked grid")
+    assert (outs[0][c["lengths"] == 0] == 0).all()
+    if not bf16:
+        oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+        oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+        oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+        assert_close(outs[0], c["attention_result"], what="attention_result vs oracle")
+
+
 @pytest.mark.parametrize("chunk,tail", [(64, 0), (128, 0), (256, 0), (512, 64), (512, 128), (1024, 256), (256, 256)])
 def test_lean_scan_many_chunks_per_row(oracle, mli, dev, chunk, tail):
     """Small chunks: up to 64 arrivals per row, rows of every chunk count side by side (uneven load)."""
