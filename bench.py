@@ -40,7 +40,8 @@ WORKLOADS = {
     "e1": ("paged", 1024, 2048, 128),
 }
 N_VOCAB = 1024
-SCAN_LEAN = "fused_decode_scan, lean (q.K^T + online softmax + softmax.V + in-kernel merge, one visit per page)"
+SCAN_LEAN = ("fused_decode_scan, lean (q.K^T + online softmax + softmax.V + in-kernel merge, one visit per page; "
+             "fused_decode_stream_kernel = equal page shares where the batch fills the chip, else fused_decode_scan_kernel)")
 SCAN_FULL = "fused_decode_scan, materialising (raw scores written; merged by fused_decode_combine)"
 
 
@@ -388,10 +389,15 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
-    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan", "scan_lean": "fused_decode_scan"}[which]
-    # the scan kernel's last template argument says whether it writes the raw scores: "..., true>" / "..., false>"
-    tail = {"scan": ", true>", "scan_lean": ", false>"}.get(which, "")
-    hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and k.endswith(tail)]
+    needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan", "scan_lean": "fused_decode_s"}[which]
+    # the chunked scan kernel's last template argument says whether it writes the raw scores ("..., true>" / "..., false>");
+    # the equal-shares kernel (fused_decode_stream_kernel) exists in the lean form only
+    if which == "scan_lean":
+        hits = [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_stream" in k] or \
+               [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_scan" in k and k.endswith(", false>")]
+    else:
+        tail = ", true>" if which == "scan" else ""
+        hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and k.endswith(tail)]
     return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
 
