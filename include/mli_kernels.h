@@ -315,7 +315,9 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
 /* Tuning / diagnostic knobs (process-wide; results are identical for every setting):
  *   "chunk_tokens"     0 = heuristic, else a power of two in [64, 1024]: tokens per workgroup of the
  *                      split-sequence kernels
- *   "nt_loads"         1 (default) = non-temporal hint on the once-read K/V stream, 0 = plain loads
+ *   "nt_loads"         non-temporal hint on the K/V stream: 2 (default) = where the rows' K/V (n_batch * n_sequence *
+ *                      emb_dim * 2 elements) exceeds 768 MiB, i.e. nothing of it survives in the 256 MiB Infinity Cache
+ *                      until the next step; 1 = always, 0 = never (plain loads)
  *   "qkt_token_batch"  4 | 8 (default) | 16: K rows a wave keeps in flight per load batch
  *   "flash_decode"     1 (default) = the paged compositions run the single-pass fused scan (each page visited
  *                      once for K and V, online softmax) when emb_dim fits (fp32 <= 2048, bf16 <= 4096);

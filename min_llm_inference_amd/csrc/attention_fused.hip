@@ -38,7 +38,7 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
 template <class E>
 bool stream_decode_applies(int B, int S, int D);
 size_t stats_region_bytes_for(int B, int S);
-int nt_loads_enabled();
+int nt_loads_for(int B, int S, int D, int esize);
 
 // number of (m, l, partial) triples a row of length L produces: full chunks + pieces of the remainder
 __host__ __device__ __forceinline__ int row_items(int L, int ct, int tail) {
@@ -599,7 +599,7 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         grid = dim3(B, nchunk + ct / tail);
         if ((size_t)B * slots * D * sizeof(float) + stats_bytes > ws_bytes) return 0;
     }
-    const bool nt = nt_loads_enabled();
+    const bool nt = nt_loads_for(B, S, D, E::kBytes);
 #define MLI_FU_LAUNCH(NJ, NT, TBR, MINW, WAVES, ...)                                                              \
     hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
                        dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \

@@ -12,7 +12,7 @@ constexpr int kBfWaves = kBfThreads / kWave;
 
 int chunk_tokens_for(int n_batch, int n_sequence);  // attention_scan.hip (same heuristics / tuning knobs)
 int sv_chunk_tokens_for(int n_batch, int n_sequence);
-int nt_loads_enabled();
+int nt_loads_for(int B, int S, int D, int esize);
 int fused_softmax_wanted(int B, int S);
 size_t stats_region_bytes_for(int B, int S);
 int launch_softmax(float*, const int*, int, int, hipStream_t);
@@ -264,7 +264,7 @@ static int launch_qkt_paged_bf16_stats(const float* q, const uint16_t* const* pa
     const int ct = chunk_tokens_for(B, S);
     const size_t smem = (size_t)D * 4 + (size_t)(ct / kPage) * 8;
     dim3 grid(B, ceil_div_i(S, ct));
-    if (nt_loads_enabled())
+    if (nt_loads_for(B, S, D, 2))
         hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, true>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct, stats);
     else
         hipLaunchKernelGGL((qkt_paged_bf16_kernel<8, false>), grid, dim3(kBfThreads), smem, st, q, page_table, lengths, qkt, S, D, ct, stats);
@@ -294,7 +294,7 @@ static int launch_softmax_v_paged_bf16_stats(float* probs, const uint16_t* const
     }
     const size_t smem = (size_t)ct * 4 + (size_t)(ct / kPage) * 8 + (size_t)kBfWaves * slice_u * 8 * 4;
     dim3 grid(B, nchunk);
-    const bool nt = nt_loads_enabled();
+    const bool nt = nt_loads_for(B, S, D, 2);
 #define MLI_SVB_LAUNCH(NJ, NT)                                                                             \
     hipLaunchKernelGGL((softmax_v_partial_bf16_kernel<NJ, NT>), grid, dim3(kBfThreads), smem, st, probs, page_table, \
                        lengths, dst, S, D, ct, nchunk, direct, stats)

@@ -42,7 +42,7 @@ __device__ unsigned long long mli_stream_trace[kStTraceSlots * 8];
 #define MLI_ST_TRACE(i) do { } while (0)
 #endif
 
-int nt_loads_enabled();             // attention_scan.hip
+int nt_loads_for(int B, int S, int D, int esize);             // attention_scan.hip
 size_t stats_region_bytes_for(int B, int S);
 
 // MAXSEG = segments (rows touched) a workgroup finishes per group: their wave partials wait in LDS for the group's merge
@@ -525,7 +525,7 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
                         (size_t)maxseg * D * sizeof(float) + (size_t)maxseg * kStWaves * kRowF * sizeof(float) +
                         (size_t)maxseg * kStWaves * sizeof(float2) + (size_t)maxseg * sizeof(int) + (8 + 3 * (size_t)maxseg + 1) * sizeof(int);
     if ((size_t)ml_per_row * sizeof(float2) > (size_t)maxseg * D * sizeof(float) || smem > 80 * 1024) return 0;
-    const bool nt = nt_loads_enabled();
+    const bool nt = nt_loads_for(B, S, D, E::kBytes);
 #define MLI_ST_LAUNCH(NJ, NT, TBR, MAXSEG)                                                                              \
     do {                                                                                                                 \
         auto kern = fused_decode_stream_kernel<E, NJ, NT, TBR, MAXSEG>;                                                  \

@@ -12,6 +12,9 @@ from min_llm_inference_amd import ops
 name = sys.argv[2] if len(sys.argv) > 2 else "c4"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 lib = _lib.load_library()
+lib.mli_tune(b"scan_stream_min_tokens", 0)
+if len(sys.argv) > 4:
+    lib.mli_tune(b"scan_stream_dynamic_pct", int(sys.argv[4]))
 wl = bench.Workload(name, torch.device("cuda:0"), 123, headroom=8, dtype=dtype)
 scan = lambda: ops.decode_scan_paged(wl.q_output, wl.page_table, wl.lengths, None, wl.attention_result, dtype == "bf16", phases=7, n_sequence=wl.S)
 for _ in range(5):
