@@ -270,7 +270,13 @@ int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float*
  * (mli_paged_attention_lean / mli_inference_self_attention) followed by the fused decoder head.  For hosts that pay per
  * call (the Python test / bench front end); the C++ layers issue the same launches themselves.
  *   paged:      q_output [n_batch, emb_dim] is scratch; attention_result [n_batch, emb_dim] holds the attention output
- *   contiguous: qkt_output [n_batch, n_sequence] is scratch as well (K^T and V are two passes) */
+ *   contiguous: qkt_output [n_batch, n_sequence] is scratch as well (K^T and V are two passes)
+ * With mli_tune "step_fused" = 1, small fp32 paged batches (both GEMMs of the step are the panel kernel's shapes and the
+ * scan runs the chunked grid with the in-kernel merge, e.g. BASELINE config 3) run the step as ONE launch whose workgroups
+ * take the four kernels' bodies as roles -- projection tiles, scan items, logits tiles, token pick -- and hand rows to
+ * each other through counters in the workspace (decode_step_fused.hip).  Results are bit-identical either way; measured
+ * slower than the separate launches (config 3: 72 vs 67 us), hence off by default.  The workspace must have been
+ * initialised once (mli_attention_workspace_init). */
 int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk, const void* wq, const void* wv,
                           const float* emb_table, const float* wpe_table, float* q_output, float* attention_result,
                           int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
@@ -283,6 +289,11 @@ int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const f
                     int n_batch, int n_sequence, int emb_dim, int n_vocab,
                     void* workspace, size_t workspace_bytes, void* decoder_scratch, size_t decoder_scratch_bytes,
                     void* stream);
+
+/* Diagnostic: the error word of the one-launch step kept in `workspace` (0 = every in-launch wait so far ended normally;
+ * 1 / 2 / 3 = a scan item / a logits tile / a token-pick workgroup gave up waiting: the step's results are then
+ * undefined).  Synchronises the device; never called by the product path. */
+int mli_debug_step_fused_error(void* workspace, size_t workspace_bytes, unsigned* code_out);
 
 /* ------------------------------------------------------------------------------------
  * hipGraph capture of a decode step.  No entry point above allocates or synchronises, so any sequence of them issued
@@ -348,6 +359,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
  *                      (zeros for the empty ones); bit-identical results
  *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
+ *   "step_fused"       1 = mli_paged_decode_step runs small fp32 paged batches as one launch (decode_step_fused.hip),
+ *                      0 (default) = always the separate launches
  *   "gemm_panel"       1 (default) = small fp32 products (emb_dim <= 512, fewer than 256 tiles of 64x64: the decode
  *                      projection and the logits of configs 2 / 3) run the latency-shaped kernel (32x32 tiles, the
  *                      whole K panel requested at once), 0 = always the tiled kernel, 2 = whenever the shape allows
