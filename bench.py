@@ -43,6 +43,8 @@ N_VOCAB = 1024
 SCAN_LEAN = ("fused_decode_scan, lean (q.K^T + online softmax + softmax.V + in-kernel merge, one visit per page; "
              "fused_decode_stream_kernel = equal page shares where the batch fills the chip, else fused_decode_scan_kernel)")
 SCAN_FULL = "fused_decode_scan, materialising (raw scores written; merged by fused_decode_combine)"
+SCAN_NAIVE = ("naive_decode_scan, lean (contiguous caches: 256-token chunks scored from the K^T tile, probabilities in LDS, "
+              "accumulated over the V tile, rows merged in-kernel)")
 
 
 class Workload:
@@ -227,13 +229,21 @@ class Workload:
                     w.q_output, w.page_table, w.lengths, w.qkt_output, w.attention_result, bf, phases=2)
                 k["decoder head (logits GEMM + argmax kernel, emb_score materialised)"] = w.decoder
             return k
+        if lean:
+            return {
+                "get_latest_kt_q_v (MFMA GEMM)": lambda: ops.launch_get_latest_kt_q_v(
+                    w.inp_embedding, w.lengths, w.wk, w.wq, w.wv, w.kt_cache, w.v_cache, w.q_output),
+                SCAN_NAIVE: lambda: ops.decode_scan_contiguous(w.q_output, w.kt_cache, w.v_cache, w.lengths,
+                                                               w.attention_result),
+                "decoder head (logits GEMM with argmax epilogue + finalize)": w.fused_decoder,
+            }
         return {
             "get_latest_kt_q_v (MFMA GEMM)": lambda: ops.launch_get_latest_kt_q_v(
                 w.inp_embedding, w.lengths, w.wk, w.wq, w.wv, w.kt_cache, w.v_cache, w.q_output),
             "qkt": lambda: ops.launch_qkt(w.q_output, w.kt_cache, w.lengths, w.qkt_output),
             "softmax_in_place_with_lengths": lambda: ops.launch_softmax_in_place_with_lengths(w.qkt_output, w.lengths),
             "softmax_v": lambda: ops.launch_softmax_v(w.qkt_output, w.v_cache, w.attention_result, w.lengths),
-            "decoder head": w.fused_decoder if lean else w.decoder,
+            "decoder head": w.decoder,
         }
 
     def algorithmic_bytes(self, lengths):
@@ -394,7 +404,8 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
     # the equal-shares kernel (fused_decode_stream_kernel) exists in the lean form only
     if which == "scan_lean":
         hits = [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_stream" in k] or \
-               [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_scan" in k and k.endswith(", false>")]
+               [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_scan" in k and k.endswith(", false>")] or \
+               [v["traffic_bytes"] for k, v in kernels.items() if "naive_decode_scan" in k]
     else:
         tail = ", true>" if which == "scan" else ""
         hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and k.endswith(tail)]
@@ -661,6 +672,8 @@ def roofline_report(wl, workload, dtype, lengths_now, ms_per_step, reps, lean=Tr
     torch.cuda.synchronize()
     if wl.layout == "paged":
         key_of = {"scan_lean" if lean else "scan": SCAN_LEAN if lean else SCAN_FULL}
+    elif lean:
+        key_of = {"scan_lean": SCAN_NAIVE}
     else:
         key_of = {"qkt": "qkt", "softmax_v": "softmax_v"}
     dom = max(key_of, key=lambda k: times[key_of[k]])

@@ -190,6 +190,24 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths,
                              int n_batch, int n_sequence, int emb_dim, int n_new_items, int elem_bf16,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* LEAN contiguous composition -- what SelfAttentionLayer::forward runs: inference_self_attention
+ * (self_attention_inference_optimized.h:22-25) without its qkt_output scratch (nothing downstream reads it,
+ * src/layers.cpp:41-56).  fill (n_new_items rows) -> latest -> ONE scan launch: a workgroup scores 256 tokens of a row
+ * from the K^T tile, keeps exp(score - chunk max) in LDS, accumulates it over the V tile, and the workgroup that
+ * completes a row merges its chunks (attention_fused_naive.hip).  attention_result differs from
+ * mli_inference_self_attention's by fp32 rounding of the merge only.  Dims must be multiples of 4 and the caches
+ * 16-byte aligned; otherwise MLI_ERR_BAD_ARG (the caller takes mli_inference_self_attention). */
+int mli_self_attention_lean(const float* inp_embedding, const int* lengths,
+                            const float* wk, const float* wq, const float* wv, const int* new_batch_idx,
+                            float* kt_cache, float* v_cache, float* q_output, float* attention_result,
+                            int n_batch, int n_sequence, int input_dim, int output_dim, int n_new_items,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* The scan launch of mli_self_attention_lean on its own: q_output from mli_get_latest_kt_q_v in, attention_result out. */
+int mli_decode_scan_contiguous(const float* q_output, const float* kt_cache, const float* v_cache, const int* lengths,
+                               float* attention_result, int n_batch, int n_sequence, int emb_dim,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* The single-pass scan the paged compositions run after the projection (scores + masked softmax + softmax.V in
  * one visit per page; what A10 -> A4 -> A11 of SURVEY 8(a) compute together).  Inputs: q_output from
  * mli_get_latest_k_q_v_paged[_bf16]; outputs: qkt_output (probabilities, zero tail) and attention_result.
@@ -267,10 +285,10 @@ int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float*
 
 /* One whole decode step of the continuous batch (n_new_items = 0) in ONE call: what *InferenceModel::forward does per
  * round once the new rows are prefilled (reference src/inference_model.cpp:26-30, 68-72) -- lean attention
- * (mli_paged_attention_lean / mli_inference_self_attention) followed by the fused decoder head.  For hosts that pay per
+ * (mli_paged_attention_lean / mli_self_attention_lean) followed by the fused decoder head.  For hosts that pay per
  * call (the Python test / bench front end); the C++ layers issue the same launches themselves.
  *   paged:      q_output [n_batch, emb_dim] is scratch; attention_result [n_batch, emb_dim] holds the attention output
- *   contiguous: qkt_output [n_batch, n_sequence] is scratch as well (K^T and V are two passes)
+ *   contiguous: qkt_output [n_batch, n_sequence] is scratch for the shapes mli_self_attention_lean does not cover
  * With mli_tune "step_fused" = 1, small fp32 paged batches (both GEMMs of the step are the panel kernel's shapes and the
  * scan runs the chunked grid with the in-kernel merge, e.g. BASELINE config 3) run the step as ONE launch whose workgroups
  * take the four kernels' bodies as roles -- projection tiles, scan items, logits tiles, token pick -- and hand rows to
@@ -359,6 +377,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
  *                      (zeros for the empty ones); bit-identical results
  *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
+ *   "naive_scan_fused" 1 (default) = mli_self_attention_lean runs the single-launch contiguous scan, 0 = it returns
+ *                      MLI_ERR_BAD_ARG (callers fall back to mli_inference_self_attention)
  *   "step_fused"       1 = mli_paged_decode_step runs small fp32 paged batches as one launch (decode_step_fused.hip),
  *                      0 (default) = always the separate launches
  *   "gemm_panel"       1 (default) = small fp32 products (emb_dim <= 512, fewer than 256 tiles of 64x64: the decode

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mli_paged_decoder_multi_rounds_bf16": [_P] * 7 + [_I] * 6 + [_P],
     "mli_decode_scan_paged": [_P] * 5 + [_I] * 5 + [_P, _Z, _P],
     "mli_paged_attention_lean": [_P] * 8 + [_I] * 5 + [_P, _Z, _P],
+    "mli_self_attention_lean": [_P] * 10 + [_I] * 5 + [_P, _Z, _P],
+    "mli_decode_scan_contiguous": [_P] * 5 + [_I] * 3 + [_P, _Z, _P],
     "mli_decoder_scratch_bytes": [_I, _I],
     "mli_decoder_fused": [_P] * 6 + [_I] * 4 + [_P, _Z, _P],
     "mli_paged_decoder_fused": [_P] * 6 + [_I] * 7 + [_P, _Z, _P],

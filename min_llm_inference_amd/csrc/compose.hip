@@ -38,6 +38,9 @@ int launch_fill_paged_embed(const float*, const float*, const int*, float* const
                             const float*, int, int, int, int, hipStream_t);
 int launch_fill_paged_bf16_embed(const float*, const float*, const int*, uint16_t* const*, const int*, const int*,
                                  const uint16_t*, const uint16_t*, int, int, int, int, hipStream_t);
+// single-launch scan over the contiguous caches (attention_fused_naive.hip): 1 = ran, 0 = shape not covered, else error + (rc > 0)
+int launch_fused_decode_naive(const float*, const float*, const float*, const int*, float*, int, int, int, void*, size_t,
+                              hipStream_t);
 // the whole step as one launch (decode_step_fused.hip): 1 = ran, 0 = not a batch for it, else error + (rc > 0)
 int launch_decode_step_fused(float* const*, int*, const float*, const float*, const float*, const float*, const float*,
                              float*, float*, int*, int, int, int, int, int, int, void*, size_t, void*, size_t, hipStream_t);
@@ -80,6 +83,27 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths, const 
     return fused < 0 ? fused : fused - 1;
 }
 
+int mli_self_attention_lean(const float* inp_embedding, const int* lengths, const float* wk, const float* wq,
+                            const float* wv, const int* new_batch_idx, float* kt_cache, float* v_cache, float* q_output,
+                            float* attention_result, int n_batch, int n_sequence, int input_dim, int output_dim,
+                            int n_new_items, void* workspace, size_t workspace_bytes, void* stream) {
+    { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
+    hipStream_t st = mli::as_stream(stream);
+    int rc = mli::launch_fill_naive(inp_embedding, new_batch_idx, lengths, wk, wv, kt_cache, v_cache, n_batch,
+                                    n_sequence, input_dim, output_dim, n_new_items, st);
+    if (rc) return rc;
+    rc = mli::launch_latest_naive(inp_embedding, lengths, wk, wq, wv, kt_cache, v_cache, q_output, n_batch,
+                                  n_sequence, input_dim, output_dim, st);
+    if (rc) return rc;
+    const int fused = mli::launch_fused_decode_naive(q_output, kt_cache, v_cache, lengths, attention_result, n_batch,
+                                                     n_sequence, output_dim, workspace, workspace_bytes, st);
+    if (fused == 1) return 0;
+    // shapes the single-launch scan does not cover (dims not multiples of 4, no workspace): the caller takes the
+    // materialising composition -- the projection it has just run is idempotent
+    if (fused == 0) return MLI_ERR_BAD_ARG;
+    return fused < 0 ? fused : fused - 1;
+}
+
 int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk, const void* wq, const void* wv,
                           const float* emb_table, const float* wpe_table, float* q_output, float* attention_result,
                           int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
@@ -110,9 +134,13 @@ int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const f
                     float* qkt_output, float* attention_result, int* decoder_result, int n_batch, int n_sequence,
                     int emb_dim, int n_vocab, void* workspace, size_t workspace_bytes, void* decoder_scratch,
                     size_t decoder_scratch_bytes, void* stream) {
-    const int rc = mli_inference_self_attention(inp_embedding, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, kt_cache,
-                                                v_cache, q_output, qkt_output, attention_result, n_batch, n_sequence,
-                                                emb_dim, emb_dim, /*n_new_items=*/0, workspace, workspace_bytes, stream);
+    int rc = mli_self_attention_lean(inp_embedding, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, kt_cache, v_cache,
+                                     q_output, attention_result, n_batch, n_sequence, emb_dim, emb_dim, /*n_new_items=*/0,
+                                     workspace, workspace_bytes, stream);
+    if (rc == MLI_ERR_BAD_ARG)  // a shape the single-launch scan does not cover: scores and probabilities through qkt_output
+        rc = mli_inference_self_attention(inp_embedding, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, kt_cache, v_cache,
+                                          q_output, qkt_output, attention_result, n_batch, n_sequence, emb_dim, emb_dim,
+                                          /*n_new_items=*/0, workspace, workspace_bytes, stream);
     if (rc) return rc;
     return mli_decoder_fused(attention_result, emb_table, wpe_table, inp_embedding, lengths, decoder_result, n_batch,
                              n_vocab, n_sequence, emb_dim, decoder_scratch, decoder_scratch_bytes, stream);

@@ -68,6 +68,89 @@ struct ScanNoGate {
     __device__ __forceinline__ void before_prefetch() const {}
 };
 
+// The tail of every item of a row that has several: the item's partial output row has been stored write-through (sc1)
+// at partial_row[c]; here its (m, l) pair follows, the arrival is counted, and the workgroup whose arrival completes the
+// row merges the row's nc triples in item order into out_row (MI355X_MICROARCH.md, inter-workgroup visibility: sc1
+// payload + every storing wave's vmcnt(0) + barrier + counter add; the last arriver: agent acquire + vmcnt(0) + barrier,
+// then loads) and puts the counter back to zero.  All THREADS threads call it.  lds: >= nc float2 of scratch no thread
+// still reads; last_sh: one LDS int.
+template <int THREADS, bool GATED, class Gate>
+__device__ __forceinline__ void row_publish_merge(float m, float l, float2* ml_row, int c, int nc, unsigned* arrival,
+                                                  const float* partial_row, int D, float* out_row, float* lds,
+                                                  int* last_sh, Gate gate, int b) {
+    typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
+    typedef unsigned __attribute__((address_space(1)))* gu32_ptr;
+    if (threadIdx.x == 0) {
+        const unsigned long long packed = ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m);
+        __hip_atomic_store((gu64_ptr)(ml_row + c), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned before = __hip_atomic_fetch_add((gu32_ptr)arrival, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = before + 1u == (unsigned)nc;
+        if (last) {
+            __hip_atomic_store((gu32_ptr)arrival, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's L1 copies of the other items' lines
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and hold the barrier until that has happened
+        }
+        *last_sh = last;
+    }
+    __syncthreads();
+    if (!*last_sh) return;
+    // item statistics -> LDS; sc1 loads: served by L2 / memory, never L1
+    float2* ml_sh = reinterpret_cast<float2*>(lds);
+    for (int i = threadIdx.x; i < nc; i += THREADS) {
+        const unsigned long long packed = __hip_atomic_load((gu64_ptr)(ml_row + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ml_sh[i] = make_float2(__uint_as_float((unsigned)packed), __uint_as_float((unsigned)(packed >> 32)));
+    }
+    __syncthreads();
+    float mm = -INFINITY;
+    for (int i = 0; i < nc; ++i) mm = fmaxf(mm, ml_sh[i].x);
+    float ll = 0.f;
+    for (int i = 0; i < nc; ++i) ll = fmaf(ml_sh[i].y, expf(ml_sh[i].x - mm), ll);
+    const float inv_l = 1.f / ll;
+    for (int d = 4 * threadIdx.x; d < D; d += 4 * THREADS) {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < nc; i0 += 8) {   // up to 8 partial rows in flight
+            fu_u32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (i0 + k < nc) {
+                    const float* row_i = partial_row + (int64_t)(i0 + k) * D;
+                    const __amdgpu_buffer_rsrc_t prow =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row_i), 0, D * (int)sizeof(float), 0x00020000);
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(prow, d * (int)sizeof(float), 0, 16);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (i0 + k < nc) {
+                    const float w = expf(ml_sh[i0 + k].x - mm);
+                    r[0] = fmaf(__uint_as_float(v[k].x), w, r[0]);
+                    r[1] = fmaf(__uint_as_float(v[k].y), w, r[1]);
+                    r[2] = fmaf(__uint_as_float(v[k].z), w, r[2]);
+                    r[3] = fmaf(__uint_as_float(v[k].w), w, r[3]);
+                }
+            }
+        }
+        if constexpr (GATED) {
+            const __amdgpu_buffer_rsrc_t orow2 = __builtin_amdgcn_make_buffer_rsrc(out_row, 0, D * (int)sizeof(float), 0x00020000);
+            fu_u32x4 raw;
+            raw.x = __float_as_uint(r[0] * inv_l); raw.y = __float_as_uint(r[1] * inv_l);
+            raw.z = __float_as_uint(r[2] * inv_l); raw.w = __float_as_uint(r[3] * inv_l);
+            __builtin_amdgcn_raw_buffer_store_b128(raw, orow2, d * (int)sizeof(float), 0, 16);  // sc1: write-through
+        } else {
+            *reinterpret_cast<float4*>(out_row + d) = make_float4(r[0] * inv_l, r[1] * inv_l, r[2] * inv_l, r[3] * inv_l);
+        }
+    }
+    if constexpr (GATED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, then the barrier, then the count
+        __syncthreads();
+        if (threadIdx.x == 0) gate.row_done(b);
+    }
+}
+
 // b, c: the item (row, grid row); first_grid_row: this workgroup is the one that writes the zero result of an empty row.
 // Gate (kGated): the row's q and newest K / V rows come from another workgroup of the SAME launch --
 //   gate.length_read(b)   after lengths[b] has been read (every path, before any return);
@@ -422,84 +505,9 @@ __device__ __forceinline__ void fused_scan_item(
         if (threadIdx.x == 0) ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
     } else {
         // ---- publish the triple, count the arrival; the workgroup that completes the row merges it ----
-        typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
-        typedef unsigned __attribute__((address_space(1)))* gu32_ptr;
-        int* last_sh = reinterpret_cast<int*>(wave_ml);  // free by now: every read of wave_ml is behind a barrier
-        float2* ml_row = ml + (int64_t)b * ml_per_row;
-        if (threadIdx.x == 0) {
-            const unsigned long long packed = ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m);
-            __hip_atomic_store((gu64_ptr)(ml_row + c), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave: its write-through stores have left
-        __syncthreads();
-        const int nc = row_items(L, ct, tail);            // items of this row that do work, i.e. arrivals to expect
-        if (threadIdx.x == 0) {
-            const unsigned before = __hip_atomic_fetch_add((gu32_ptr)(arrivals + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = before + 1u == (unsigned)nc;
-            if (last) {
-                __hip_atomic_store((gu32_ptr)(arrivals + b), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's L1 copies of the other chunks' lines
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and hold the barrier until that has happened
-            }
-            *last_sh = last;
-        }
-        __syncthreads();
-        if (*last_sh) {
-            // chunk statistics -> LDS (the scan's reduction buffer is free now); sc1 loads: served by L2 / memory, never L1
-            float2* ml_sh = reinterpret_cast<float2*>(red);
-            for (int i = threadIdx.x; i < nc; i += (WAVES * kWave)) {
-                const unsigned long long packed = __hip_atomic_load((gu64_ptr)(ml_row + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ml_sh[i] = make_float2(__uint_as_float((unsigned)packed), __uint_as_float((unsigned)(packed >> 32)));
-            }
-            __syncthreads();
-            float mm = -INFINITY;
-            for (int i = 0; i < nc; ++i) mm = fmaxf(mm, ml_sh[i].x);
-            float ll = 0.f;
-            for (int i = 0; i < nc; ++i) ll = fmaf(ml_sh[i].y, expf(ml_sh[i].x - mm), ll);
-            const float inv_l = 1.f / ll;
-            const float* pr = partial + (int64_t)b * slots * D;
-            for (int d = 4 * threadIdx.x; d < D; d += 4 * (WAVES * kWave)) {
-                float r[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int i0 = 0; i0 < nc; i0 += 8) {   // up to 8 chunk rows in flight
-                    fu_u32x4 v[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (i0 + k < nc) {
-                            const float* row_i = pr + (int64_t)(i0 + k) * D;
-                            const __amdgpu_buffer_rsrc_t prow =
-                                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row_i), 0, D * (int)sizeof(float), 0x00020000);
-                            v[k] = __builtin_amdgcn_raw_buffer_load_b128(prow, d * (int)sizeof(float), 0, 16);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (i0 + k < nc) {
-                            const float w = expf(ml_sh[i0 + k].x - mm);
-                            r[0] = fmaf(__uint_as_float(v[k].x), w, r[0]);
-                            r[1] = fmaf(__uint_as_float(v[k].y), w, r[1]);
-                            r[2] = fmaf(__uint_as_float(v[k].z), w, r[2]);
-                            r[3] = fmaf(__uint_as_float(v[k].w), w, r[3]);
-                        }
-                    }
-                }
-                if constexpr (GATED) {
-                    float* orow_p = out + (int64_t)b * D;
-                    const __amdgpu_buffer_rsrc_t orow2 = __builtin_amdgcn_make_buffer_rsrc(orow_p, 0, D * (int)sizeof(float), 0x00020000);
-                    fu_u32x4 raw;
-                    raw.x = __float_as_uint(r[0] * inv_l); raw.y = __float_as_uint(r[1] * inv_l);
-                    raw.z = __float_as_uint(r[2] * inv_l); raw.w = __float_as_uint(r[3] * inv_l);
-                    __builtin_amdgcn_raw_buffer_store_b128(raw, orow2, d * (int)sizeof(float), 0, 16);  // sc1: write-through
-                } else {
-                    *reinterpret_cast<float4*>(out + (int64_t)b * D + d) =
-                        make_float4(r[0] * inv_l, r[1] * inv_l, r[2] * inv_l, r[3] * inv_l);
-                }
-            }
-            if constexpr (GATED) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, then the barrier, then the count
-                __syncthreads();
-                if (threadIdx.x == 0) gate.row_done(b);
-            }
-        }
+        row_publish_merge<WAVES * kWave, GATED>(m, l, ml + (int64_t)b * ml_per_row, c, row_items(L, ct, tail), arrivals + b,
+                                                partial + (int64_t)b * slots * D, D, out + (int64_t)b * D, red,
+                                                reinterpret_cast<int*>(wave_ml), gate, b);
     }
     MLI_TRACE(4);
 #ifdef MLI_SCAN_TRACE

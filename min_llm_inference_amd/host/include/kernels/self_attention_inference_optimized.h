@@ -32,6 +32,14 @@ void inference_self_attention(const TensorFloat& inp_embedding, const TensorInt&
                               TensorFloat& kt_cache, TensorFloat& v_cache, TensorFloat& q_output,
                               TensorFloat& qkt_output, TensorFloat& attention_result, int n_new_items);
 
+// EXTENSION: the composition without the scores (include/mli_kernels.h: mli_self_attention_lean); shapes its single-launch
+// scan does not cover take inference_self_attention through the caller's qkt_output scratch.  What
+// SelfAttentionLayer::forward runs unless runtime::set_lean_layers(false).
+void inference_self_attention_lean(const TensorFloat& inp_embedding, const TensorInt& lengths, const TensorFloat& wk,
+                                   const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
+                                   TensorFloat& kt_cache, TensorFloat& v_cache, TensorFloat& q_output,
+                                   TensorFloat& qkt_output, TensorFloat& attention_result, int n_new_items);
+
 // EXTENSION: launch_inference_optimized_encoder_kernel + launch_fill_new_kt_v_cache in one launch --
 // the embedding lookup is the fill GEMM's prologue; inp_embedding, kt_cache and v_cache bit-identical to the two launches.
 void launch_prefill(const TensorFloat& emb_table, const TensorFloat& wpe, const TensorInt& inp,

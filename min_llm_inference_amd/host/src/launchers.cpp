@@ -163,6 +163,25 @@ void inference_self_attention(const TensorFloat& inp_embedding, const TensorInt&
                                            out_dim, n_new_items, ws.ptr, ws.bytes, stream()));
 }
 
+void inference_self_attention_lean(const TensorFloat& inp_embedding, const TensorInt& lengths, const TensorFloat& wk,
+                                   const TensorFloat& wq, const TensorFloat& wv, const TensorInt& new_batch_idx,
+                                   TensorFloat& kt_cache, TensorFloat& v_cache, TensorFloat& q_output,
+                                   TensorFloat& qkt_output, TensorFloat& attention_result, int n_new_items) {
+    const auto& s = inp_embedding.shape();
+    const int out_dim = (int)wk.shape()[1];
+    const Scratch ws = scratch_for((int)s[0], (int)s[1], out_dim);
+    const int rc = mli_self_attention_lean(inp_embedding.data(), lengths.data(), wk.data(), wq.data(), wv.data(),
+                                           new_batch_idx.data(), kt_cache.data(), v_cache.data(), q_output.data(),
+                                           attention_result.data(), (int)s[0], (int)s[1], (int)s[2], out_dim, n_new_items,
+                                           ws.ptr, ws.bytes, stream());
+    if (rc == MLI_ERR_BAD_ARG) {
+        inference_self_attention(inp_embedding, lengths, wk, wq, wv, new_batch_idx, kt_cache, v_cache, q_output, qkt_output,
+                                 attention_result, n_new_items);
+        return;
+    }
+    HIP_CHECK(rc);
+}
+
 // ---- paged layout -----------------------------------------------------------------------------------
 void launch_fill_new_k_v_cache_paged_attention(TensorFloatPoint page_table, const TensorInt& new_batch_idx,
                                                const TensorInt& lengths, const TensorFloat& wk,

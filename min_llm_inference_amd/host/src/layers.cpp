@@ -24,8 +24,12 @@ SelfAttentionLayer::SelfAttentionLayer(TensorFloat&& wk, TensorFloat&& wq, Tenso
 
 void SelfAttentionLayer::forward(const TensorFloat& inp_embedding, const TensorInt& lengths,
                                  const TensorInt& new_batch_idx, TensorFloat& attention_result, int n_new_items) {
-    inference_self_attention(inp_embedding, lengths, wk_, wq_, wv_, new_batch_idx, kt_cache_, v_cache_, q_output_,
-                             qkt_output_, attention_result, n_new_items);
+    if (mli::runtime::lean_layers())
+        inference_self_attention_lean(inp_embedding, lengths, wk_, wq_, wv_, new_batch_idx, kt_cache_, v_cache_, q_output_,
+                                      qkt_output_, attention_result, n_new_items);
+    else
+        inference_self_attention(inp_embedding, lengths, wk_, wq_, wv_, new_batch_idx, kt_cache_, v_cache_, q_output_,
+                                 qkt_output_, attention_result, n_new_items);
 }
 
 void SelfAttentionLayer::prefill(const TensorFloat& emb_table, const TensorFloat& pos_emb, const TensorInt& inp,

@@ -102,6 +102,27 @@ def inference_self_attention(inp_embedding, lengths, wk, wq, wv, new_batch_idx, 
         "mli_inference_self_attention")
 
 
+def self_attention_lean(inp_embedding, lengths, wk, wq, wv, new_batch_idx, kt_cache, v_cache, q_output, attention_result,
+                        n_new_items):
+    """What SelfAttentionLayer runs: the contiguous composition without the qkt_output scratch (mli_self_attention_lean)."""
+    B, S, Din = inp_embedding.shape
+    Dout = wk.shape[1]
+    ws, need = workspace_for(B, S, Dout, inp_embedding.device)
+    _check(load_library().mli_self_attention_lean(
+        _p(inp_embedding), _p(lengths), _p(wk), _p(wq), _p(wv), _p(new_batch_idx), _p(kt_cache), _p(v_cache),
+        _p(q_output), _p(attention_result), B, S, Din, Dout, n_new_items, _p(ws), need, _stream()),
+        "mli_self_attention_lean")
+
+
+def decode_scan_contiguous(q_output, kt_cache, v_cache, lengths, attention_result):
+    """The single-launch scan of the lean contiguous composition on its own (mli_decode_scan_contiguous)."""
+    B, D, S = kt_cache.shape
+    ws, need = workspace_for(B, S, D, q_output.device)
+    _check(load_library().mli_decode_scan_contiguous(_p(q_output), _p(kt_cache), _p(v_cache), _p(lengths),
+                                                     _p(attention_result), B, S, D, _p(ws), need, _stream()),
+           "mli_decode_scan_contiguous")
+
+
 # ---- paged path (page_table: int64 [B, S/16] tensor of device addresses) -----------------------
 def launch_fill_new_k_v_cache_paged_attention(page_table, new_batch_idx, lengths, wk, wv, n_new_items, n_sequence):
     B = page_table.shape[0]

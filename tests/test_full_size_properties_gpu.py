@@ -277,7 +277,9 @@ def test_config2_full_size_step_matches_the_oracle(oracle, mli, dev):
     wl.attention_result.zero_()
     wl.lean_step()
     torch.cuda.synchronize()
-    assert torch.equal(wl.attention_result, first)
+    # (the lean composition keeps the probabilities in LDS and merges 256-token chunks: fp32 rounding of the merge apart)
+    assert_close(wl.attention_result.cpu().numpy(), first.cpu().numpy(), thr=2e-5, what="lean vs materialising")
+    assert_close(wl.attention_result.cpu().numpy(), o, what="attention_result of the lean step")
     tok = wl.decoder_result.view(-1).cpu().numpy()
     logits = o @ wl.emb_table.cpu().numpy().T
     best = logits.max(axis=1)

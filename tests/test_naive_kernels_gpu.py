@@ -134,3 +134,78 @@ def test_config1_exact_lengths(oracle, mli, dev):
     for k in ("attention_result", "q_output", "qkt_output", "kt_cache", "v_cache"):
         assert_close(host(d[k]), c[k], what=k)
     assert (host(d["attention_result"])[0] == 0).all()  # empty row -> zeros
+
+
+# ---- the lean contiguous composition: one scan launch, no scores / probabilities in memory -----------------------
+# (seed, B, S, Din, Dout): one chunk per row; several chunks, ragged; config 2 reduced; 512- and 1024-wide rows (two lane
+# loads per V row / swept in slices); many short rows; S not a multiple of the chunk
+LEAN_SHAPES = [(21, 33, 400, 257, 100), (22, 100, 800, 128, 128), (23, 4, 128, 64, 64), (24, 16, 1024, 256, 256),
+               (25, 9, 2048, 64, 512), (26, 5, 516, 96, 1024), (27, 300, 260, 32, 36)]
+
+
+@pytest.mark.parametrize("conditioned,zero_every", [(False, None), (True, 5)])
+@pytest.mark.parametrize("seed,B,S,Din,Dout", LEAN_SHAPES)
+def test_self_attention_lean(oracle, mli, dev, seed, B, S, Din, Dout, conditioned, zero_every):
+    """mli_self_attention_lean (what SelfAttentionLayer runs) against the oracle's composition and against
+    mli_inference_self_attention on the same inputs: same caches and q_output bit for bit, attention_result within the
+    merge's fp32 rounding, qkt_output never touched."""
+    from helpers import assert_equal
+    from min_llm_inference_amd import ops
+    c = naive_case(seed, B, S, Din, Dout, conditioned=conditioned, zero_every=zero_every)
+    lean, full = to_dev(c, dev), to_dev(c, dev)
+    ops.self_attention_lean(lean["inp"], lean["lengths"], lean["wk"], lean["wq"], lean["wv"], lean["new_batch_idx"],
+                            lean["kt_cache"], lean["v_cache"], lean["q_output"], lean["attention_result"], c["n_new"])
+    ops.inference_self_attention(full["inp"], full["lengths"], full["wk"], full["wq"], full["wv"], full["new_batch_idx"],
+                                 full["kt_cache"], full["v_cache"], full["q_output"], full["qkt_output"],
+                                 full["attention_result"], c["n_new"])
+    scratch_before = c["qkt_output"].copy()
+    oracle.self_attention_inference_host(c["inp"], c["lengths"], c["wk"], c["wq"], c["wv"], c["new_batch_idx"],
+                                         c["kt_cache"], c["v_cache"], c["q_output"], c["qkt_output"],
+                                         c["attention_result"], c["n_new"])
+    got = host(lean["attention_result"])
+    if conditioned:
+        assert_close(got, c["attention_result"], what="attention_result vs oracle")
+    else:
+        # reference distribution: scores of ~1e4 with an ulp of 1e-3 and a near-one-hot softmax -- a row whose two best
+        # scores are within a few ulps turns one ulp of score rounding into 1e-3 of the result; compare where the
+        # softmax is well-posed (helpers.well_posed_rows, as the probabilities of the materialising form are compared)
+        from helpers import well_posed_rows
+        raw = np.zeros_like(c["qkt_output"])
+        oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], raw)
+        ok = well_posed_rows(raw, c["lengths"]) | (c["lengths"] == 0)
+        assert ok.sum() >= max(1, B // 4)
+        assert_close(got[ok], c["attention_result"][ok], what="attention_result vs oracle (well-posed rows)")
+    # the scores are computed exactly as launch_qkt computes them: the two forms differ by the merge's rounding only
+    assert_close(got, host(full["attention_result"]), thr=2e-5, what="attention_result vs the materialising composition")
+    for k in ("q_output", "kt_cache", "v_cache"):
+        assert_equal(host(lean[k]), host(full[k]), what=k)
+    assert_equal(host(lean["qkt_output"]), scratch_before, what="qkt_output must not be touched")
+
+
+def test_self_attention_lean_chunk_edges(oracle, mli, dev):
+    """Lengths on and around the 256-token chunk boundaries, the empty row, a single token, the full row."""
+    from min_llm_inference_amd import ops
+    L = [0, 1, 17, 255, 256, 257, 511, 512, 513, 768, 1023, 1024]
+    c = naive_case(102, len(L), 1024, 64, 128, conditioned=True, lengths=L)
+    c["n_new"] = 0
+    d = to_dev(c, dev)
+    ops.self_attention_lean(d["inp"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["kt_cache"],
+                            d["v_cache"], d["q_output"], d["attention_result"], 0)
+    oracle.self_attention_inference_host(c["inp"], c["lengths"], c["wk"], c["wq"], c["wv"], c["new_batch_idx"],
+                                         c["kt_cache"], c["v_cache"], c["q_output"], c["qkt_output"],
+                                         c["attention_result"], 0)
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result")
+    # repeated launches: the rows' arrival counters are back at zero
+    ops.self_attention_lean(d["inp"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["kt_cache"],
+                            d["v_cache"], d["q_output"], d["attention_result"], 0)
+    assert_close(host(d["attention_result"]), c["attention_result"], what="attention_result, second launch")
+
+
+def test_self_attention_lean_refuses_what_it_does_not_cover(mli, dev):
+    """Dims that are not multiples of 4: MLI_ERR_BAD_ARG (the C++ adapter then takes inference_self_attention)."""
+    from min_llm_inference_amd import ops
+    c = naive_case(103, 7, 412, 101, 257)
+    d = to_dev(c, dev)
+    with pytest.raises(ops.MliError):
+        ops.self_attention_lean(d["inp"], d["lengths"], d["wk"], d["wq"], d["wv"], d["new_batch_idx"], d["kt_cache"],
+                                d["v_cache"], d["q_output"], d["attention_result"], c["n_new"])
