@@ -141,6 +141,10 @@ __global__ __launch_bounds__(kEdThreads) void decoder_finalize_kernel(
         if (lane == 0) decoder_result[(int64_t)b * n_decoder_results + i_decoder] = MLI_EMPTY_ROW_TOKEN_ID;
         return;
     }
+    // the page of the next position depends on the length only: requested together with the row's pairs, not behind
+    // the token (one dependent memory round trip less in a kernel that is nothing but such round trips)
+    float* page = nullptr;
+    if (PAGED && L + 1 < S) page = page_table[(int64_t)b * (S / kPage) + L / kPage];  // same address in every lane: one request
     float mv = -FLT_MAX;
     int mi = -1;
     for (int t = lane; t < n_tiles; t += kWave) {
@@ -155,8 +159,6 @@ __global__ __launch_bounds__(kEdThreads) void decoder_finalize_kernel(
     }
     const int tok = mi;  // every lane holds the same pair now
     const bool done = (L + 1 >= S) || tok == MLI_EOF_TOKEN_ID;
-    float* page = nullptr;
-    if (PAGED && !done) page = page_table[(int64_t)b * (S / kPage) + L / kPage];  // same address in every lane: one request
     if (lane == 0) {
         decoder_result[(int64_t)b * n_decoder_results + i_decoder] = tok;
         lengths[b] = done ? 0 : L + 1;
