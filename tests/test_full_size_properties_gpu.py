@@ -285,3 +285,26 @@ def test_config2_full_size_step_matches_the_oracle(oracle, mli, dev):
     best = logits.max(axis=1)
     assert (logits[idx, tok] >= best - 1e-3).all(), "decoder token = an argmax of the oracle's logits (1e-3)"
     assert (wl.lengths.cpu().numpy() == L + 1).all()
+
+
+def test_config2_lean_scan_repeated_launches_with_changing_lengths(mli, dev):
+    """The contiguous single-launch scan at config 2's size, 40 launches back to back with fresh random lengths each
+    time (empty rows, single tokens, chunk boundaries, full rows), each against the three-launch composition on the same
+    state: the rows' in-kernel merges (arrival counters, write-through partial rows) under load."""
+    from min_llm_inference_amd import ops
+    wl = _workload("c2", dev, "f32")
+    rng = np.random.default_rng(20260)
+    want = torch.empty_like(wl.attention_result)
+    wl.q_output.copy_(torch.rand(wl.B, wl.D, device=dev) * 2 - 1)
+    special = np.array([0, 1, 255, 256, 257, 512, 513, 1023, 1024], np.int32)
+    for it in range(40):
+        L = rng.integers(0, wl.S + 1, size=wl.B).astype(np.int32)
+        L[rng.integers(0, wl.B, size=len(special))] = special
+        wl.lengths.copy_(torch.from_numpy(L).to(dev))
+        ops.launch_qkt(wl.q_output, wl.kt_cache, wl.lengths, wl.qkt_output)
+        ops.launch_softmax_in_place_with_lengths(wl.qkt_output, wl.lengths)
+        ops.launch_softmax_v(wl.qkt_output, wl.v_cache, want, wl.lengths)
+        wl.attention_result.fill_(7.0)
+        ops.decode_scan_contiguous(wl.q_output, wl.kt_cache, wl.v_cache, wl.lengths, wl.attention_result)
+        torch.cuda.synchronize()
+        assert_close(wl.attention_result.cpu().numpy(), want.cpu().numpy(), thr=2e-5, what=f"launch {it}")
