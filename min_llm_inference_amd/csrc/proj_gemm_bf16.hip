@@ -31,6 +31,17 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
+// -DMLI_GEMM_TRACE: where the k loop of the first workgroups spends its cycles (tools/gemm_trace.py) -- never the product
+#ifdef MLI_GEMM_TRACE
+constexpr int kGemmTraceWgs = 1024;
+__device__ unsigned long long mli_gemm_trace[kGemmTraceWgs * 8];
+#define MLI_GT(var) const unsigned long long var = clock64()
+#define MLI_GT_ADD(i, a, b) do { if (threadIdx.x == 0) gt_acc[i] += (b) - (a); } while (0)
+#else
+#define MLI_GT(var) do { } while (0)
+#define MLI_GT_ADD(i, a, b) do { } while (0)
+#endif
+
 union Frag8 {
     bf16x8_t v;
     uint4 u;
@@ -167,11 +178,18 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     const unsigned b_off = (unsigned)((8 * lh + tq) * kLdbBytes + (grp_col + 4 * tp) * 2);
 
     const int nk = (g.K + HK - 1) / HK;
+#ifdef MLI_GEMM_TRACE
+    unsigned long long gt_acc[5] = {0, 0, 0, 0, 0};
+    const unsigned long long gt_begin = clock64();
+#endif
     load_tile(0);
     store_tile();
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
+        MLI_GT(g0);
         if (t + 1 < nk) load_tile((t + 1) * HK);
+        MLI_GT(g1);
+        MLI_GT_ADD(0, g0, g1);
 #pragma unroll
         for (int kk = 0; kk < HK; kk += 16) {
             Frag8 b;
@@ -184,12 +202,31 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mt], 0, 0, 0);
             }
         }
+        MLI_GT(g2);
+        MLI_GT_ADD(1, g1, g2);
         __syncthreads();
+        MLI_GT(g3);
+        MLI_GT_ADD(2, g2, g3);
         if (t + 1 < nk) {
             store_tile();
+            MLI_GT(g4);
+            MLI_GT_ADD(3, g3, g4);
             __syncthreads();
+            MLI_GT(g5);
+            MLI_GT_ADD(4, g4, g5);
         }
     }
+#ifdef MLI_GEMM_TRACE
+    {
+        const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (threadIdx.x == 0 && wg < (unsigned)kGemmTraceWgs) {
+            for (int i = 0; i < 5; ++i) mli_gemm_trace[wg * 8 + i] = gt_acc[i];
+            mli_gemm_trace[wg * 8 + 5] = clock64() - gt_begin;
+            mli_gemm_trace[wg * 8 + 6] = gt_begin;
+            mli_gemm_trace[wg * 8 + 7] = (unsigned long long)nk;
+        }
+    }
+#endif
 
     // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
 #pragma unroll
@@ -260,3 +297,10 @@ int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_id
 }
 
 }  // namespace mli
+
+#ifdef MLI_GEMM_TRACE
+extern "C" int mli_debug_gemm_trace(unsigned long long* host, int n_wgs) {
+    if (n_wgs > mli::kGemmTraceWgs) n_wgs = mli::kGemmTraceWgs;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mli::mli_gemm_trace), (size_t)n_wgs * 8 * sizeof(unsigned long long));
+}
+#endif
