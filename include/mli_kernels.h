@@ -379,6 +379,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
  *   "naive_scan_fused" 1 (default) = mli_self_attention_lean runs the single-launch contiguous scan, 0 = it returns
  *                      MLI_ERR_BAD_ARG (callers fall back to mli_inference_self_attention)
+ *   "scan_row_order"   1 (default) = single-pass scans with one workgroup per row (short sequences) and more than 512 rows
+ *                      hand the rows out longest first, 0 = in grid order (identical results)
  *   "gemm_bf16_split"  1 (default) = the bf16 decode projection of a large batch (>= 1024 rows, emb_dim >= 1024, a multiple
  *                      of 128) runs the loader-wave / MFMA-wave kernel, 0 = the 128 x 64 tiled kernel (identical results)
  *   "step_fused"       1 = mli_paged_decode_step runs small fp32 paged batches as one launch (decode_step_fused.hip),

@@ -25,6 +25,73 @@ bool stream_decode_applies(int B, int S, int D);
 size_t stats_region_bytes_for(int B, int S);
 int nt_loads_for(int B, int S, int D, int esize);
 
+// One workgroup per row (short sequences: the whole row is one item): workgroups start in grid order and the rows' lengths
+// are ragged, so whichever long rows happen to sit at the end of the grid run alone at the end (README workload, B=1024,
+// S=128, D=2048: 5.3 TB/s against 6.4 with equal lengths).  This hands the rows out LONGEST FIRST instead: workgroup r takes
+// the row of rank r by page count (descending; equal counts in row order).  Every workgroup derives the same ranking from
+// the lengths -- a histogram over the page counts, then the j-th row of its bucket by a block-wide count --: ~2 us of
+// prologue per workgroup, no pre-pass, deterministic.  All kFuThreads threads call it; n_batch <= kMaxOrderedRows.
+constexpr int kMaxOrderedRows = 2048;
+constexpr int kMaxOrderedPages = 64;
+__device__ __forceinline__ int longest_first_row(const int* __restrict__ lengths, int n_batch, int S, int rank) {
+    __shared__ int hist[kMaxOrderedPages + 1];
+    __shared__ int wave_cnt[kFuWaves];
+    __shared__ int found_row;
+    constexpr int kPer = kMaxOrderedRows / kFuThreads;
+    const int tid = threadIdx.x;
+    const int per = (n_batch + kFuThreads - 1) / kFuThreads;  // rows per thread, a contiguous segment
+    if (tid <= kMaxOrderedPages) hist[tid] = 0;
+    __syncthreads();
+    int pages[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int row = tid * per + j;
+        pages[j] = -1;
+        if (j < per && row < n_batch) {
+            pages[j] = (min(max(lengths[row], 0), S) + kPage - 1) / kPage;
+            atomicAdd(&hist[pages[j]], 1);
+        }
+    }
+    __syncthreads();
+    // the bucket of this rank (page counts descending) and the rank inside it
+    int bucket = 0, before = 0;
+    for (int p = kMaxOrderedPages; p >= 0; --p) {
+        const int h = hist[p];
+        if (rank < before + h) {
+            bucket = p;
+            break;
+        }
+        before += h;
+    }
+    const int j_in_bucket = rank - before;
+    // the j-th row of the bucket in row order: matches per thread segment, exclusive prefix over the threads
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) mine += pages[j] == bucket;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kWave);
+        if ((tid & (kWave - 1)) >= off) incl += up;
+    }
+    if ((tid & (kWave - 1)) == kWave - 1) wave_cnt[tid / kWave] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < tid / kWave; ++w) base += wave_cnt[w];
+    if (j_in_bucket >= base && j_in_bucket < base + mine) {
+        int seen = base;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (pages[j] == bucket) {
+                if (seen == j_in_bucket) found_row = tid * per + j;
+                ++seen;
+            }
+        }
+    }
+    __syncthreads();
+    return found_row;
+}
+
 template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false, bool SCORES = true>
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
@@ -43,6 +110,9 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     // whose total length differs from the others' by +-10 % (tools/scan_trace.py: XCDs done at 615 .. 701 us).
     int c = blockIdx.y;
     int b = (int)((blockIdx.x + (unsigned)c) % gridDim.x);
+    if constexpr (WAVES * kWave == kFuThreads) {
+        if (direct == 2) b = longest_first_row(lengths, (int)gridDim.x, S, (int)blockIdx.x);
+    }
     if (ticket != nullptr) {
         __shared__ unsigned item_sh;
         if (threadIdx.x == 0) item_sh = atomicAdd(ticket, 1u);
@@ -112,6 +182,8 @@ static int g_dynamic_items = 0;
 void set_dynamic_items(int v) { g_dynamic_items = v != 0; }
 // mli_tune "scan_merge" (lean mode only): 1 (default) = the workgroup that completes a row merges its chunks inside
 // the scan launch, 0 = the separate combine launch (bit-identical results)
+static int g_row_order = 1;  // mli_tune "scan_row_order": 0 = one-workgroup-per-row grids take the rows in grid order
+void set_row_order(int v) { g_row_order = v != 0; }
 static int g_scan_merge = 1;
 void set_scan_merge(int v) { g_scan_merge = v != 0; }
 void set_flash_decode(int v) { g_flash = v != 0; }
@@ -157,7 +229,9 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     // chunks (README workload, S = 128: 200 vs 209 us)
     const int ct = solo ? 128 : (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : fused_chunk_tokens(B, S);
     const int nchunk = ceil_div_i(S, ct);
-    const int direct = nchunk == 1;
+    // one workgroup per row: hand the rows out longest first where the batch has more rows than the chip has workgroup slots
+    const bool ordered = g_row_order && nchunk == 1 && !solo && B > 512 && B <= kMaxOrderedRows && S / kPage <= kMaxOrderedPages;
+    const int direct = nchunk == 1 ? (ordered ? 2 : 1) : 0;
     const size_t stats_bytes = stats_region_bytes_for(B, S);
     float2* ml = nullptr;
     float* partial = nullptr;

@@ -32,7 +32,7 @@ def _t(a, dev):
 
 # (seed, B, S, D): single chunk, several chunks with ragged lengths, wide rows (the waves split the row), odd width
 SCAN_SHAPES = [(131, 24, 256, 512), (132, 9, 1024, 256), (133, 6, 4096, 512), (134, 40, 64, 64), (135, 12, 128, 2048),
-               (136, 7, 2048, 1024), (137, 5, 4096, 1540), (138, 300, 1024, 128)]
+               (136, 7, 2048, 1024), (137, 5, 4096, 1540), (138, 300, 1024, 128), (139, 700, 128, 64), (140, 1100, 32, 512)]
 
 
 @pytest.mark.parametrize("merge", [1, 0])
@@ -295,6 +295,31 @@ def test_decoder_fused_needs_its_scratch(mli, dev):
     rc = mli.mli_decoder_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), i4.data_ptr(), i4.data_ptr(),
                                4, 64, 64, 64, None, 0, None)
     assert rc == -12  # MLI_ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("seed,B,S,D", [(141, 1000, 128, 128), (142, 2048, 48, 64), (143, 513, 64, 1024)])
+def test_rows_handed_out_longest_first_change_nothing(oracle, mli, dev, seed, B, S, D):
+    """One-workgroup-per-row grids (short sequences, more rows than workgroup slots) take the rows longest first
+    (mli_tune "scan_row_order"): a permutation of which workgroup does which row -- every row's result must be bit-identical
+    to the grid-order form, lean and materialising, with empty rows and equal lengths in the mix."""
+    from min_llm_inference_amd import ops
+    c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=9)
+    res = []
+    try:
+        for order in (1, 0):
+            assert mli.mli_tune(b"scan_row_order", order) == 0
+            out_lean = torch.full((B, D), SENTINEL, device=dev)
+            out_full = torch.full((B, D), SENTINEL, device=dev)
+            qkt = torch.full((B, S), SENTINEL, device=dev)
+            ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], None, out_lean, False, phases=7, n_sequence=S)
+            ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], qkt, out_full, False, phases=3)
+            res.append((host(out_lean), host(out_full), host(qkt)))
+    finally:
+        mli.mli_tune(b"scan_row_order", 1)
+    for k, what in enumerate(("lean attention_result", "materialising attention_result", "probabilities")):
+        assert_equal(res[0][k], res[1][k], what=what)
+    assert_equal(res[0][0], res[0][1], what="lean vs materialising")
+    assert (res[0][0] != SENTINEL).all()
 
 
 # ---- a decode step replayed from a hipGraph ----------------------------------------------------------------------
