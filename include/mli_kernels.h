@@ -381,6 +381,9 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      MLI_ERR_BAD_ARG (callers fall back to mli_inference_self_attention)
  *   "scan_row_order"   1 (default) = single-pass scans with one workgroup per row (short sequences) and more than 512 rows
  *                      hand the rows out longest first, 0 = in grid order (identical results)
+ *   "gemm_split"       1 (default) = the fp32 GEMM with 64-row tiles (prefill, logits, projections of batches that do not
+ *                      fill the chip with 128-row tiles) runs as 512-thread workgroups, four waves loading and four
+ *                      multiplying, when the reduction is >= 256 long; 0 = one wave does both (identical results)
  *   "gemm_bf16_split"  1 (default) = the bf16 decode projection of a large batch (>= 1024 rows, emb_dim >= 1024, a multiple
  *                      of 128) runs the loader-wave / MFMA-wave kernel, 0 = the 128 x 64 tiled kernel (identical results)
  *   "step_fused"       1 = mli_paged_decode_step runs small fp32 paged batches as one launch (decode_step_fused.hip),

@@ -33,6 +33,7 @@ void set_stream_granule(int v);
 void set_dynamic_items(int v);
 void set_partial_last(int v);
 void set_step_fused(int v);
+void set_gemm_split(int v);
 void set_row_order(int v);
 void set_bf16_split(int v);
 void set_naive_fused(int v);
@@ -710,6 +711,8 @@ int mli_tune(const char* key, int value) {
         mli::set_bf16_split(value);
     } else if (k == "scan_row_order") {
         mli::set_row_order(value);
+    } else if (k == "gemm_split") {
+        mli::set_gemm_split(value);
     } else if (k == "step_fused") {
         mli::set_step_fused(value);
     } else if (k == "scan_partial_last") {

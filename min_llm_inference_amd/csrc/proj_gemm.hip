@@ -54,14 +54,17 @@ __device__ __forceinline__ void argmax_butterfly_step(float (&v)[16], int (&ix)[
     }
 }
 
-template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, int KQ = 1>
-__global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
+template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 2 * kGemmThreads : kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup
-    constexpr int BK = 32 * KQ;   // shadows the namespace-level 32: k extent of a staged tile
+    constexpr int BK = 32;        // k extent of a staged tile
+    constexpr int KQ = 1;
     constexpr int LDA = BM + 1;
-    __shared__ float As[BK * LDA];
+    constexpr int kBufs = SPLIT ? 2 : 1;
+    constexpr int kThreads = SPLIT ? 2 * kGemmThreads : kGemmThreads;
+    __shared__ float As[kBufs * BK * LDA];
     constexpr int LDBX = BT ? LDBT : LDB;
-    __shared__ __align__(16) float Bs[BK * LDBX];
+    __shared__ __align__(16) float Bs[kBufs * BK * LDBX];
     __shared__ const float* a_ptr[BM];
     __shared__ float* o_ptr[BM];
     constexpr bool kFillMode = MODE == kNaiveFill || MODE == kPagedFill;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     int fill_total = 0;
     if (kFill || kLatest) {
         if (g.compact) {
-            fill_total = build_fill_index<kGemmThreads, kLatest>(g, fill_index[0]);
+            fill_total = build_fill_index<kThreads, kLatest>(g, fill_index[0]);
             if (m0 >= fill_total) return;  // workgroup-uniform
         } else if (kFill && m0 >= g.lengths[g.new_batch_idx[z]]) {
             return;  // whole tile beyond the row's length: nothing to do (reference …optimized.cu:43-45)
@@ -115,8 +118,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     const int64_t o_stride = transposed_out ? g.S : 1;
     __syncthreads();
 
+    // SPLIT: threads 0..255 (waves 0-3) multiply, threads 256..511 (waves 4-7) move the next tile into the other LDS buffer
+    const bool is_loader = SPLIT && tid >= kGemmThreads;
+    const int st = is_loader ? tid - kGemmThreads : tid;   // index among the staging threads
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) & 3;
     const int wm = (wave >> 1) * 32 * MT;
     const int wn = (wave & 1) * 32;
 
@@ -124,8 +130,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     //   A tile [BM][BK]: 8 threads per row (float4 along k), 32 rows per pass, 2 passes
     //   B tile [BK][BN]: 16 threads per k-row (float4 along n), 16 k-rows per pass, 2 passes
     //   B^T tile (BT): rows are n, float4 along k -- same shape as the A tile
-    const int a_row = tid >> 3, a_kq = (tid & 7) * 4;
-    const int b_row = tid >> 4, b_nq = (tid & 15) * 4;
+    const int a_row = st >> 3, a_kq = (st & 7) * 4;
+    const int b_row = st >> 4, b_nq = (st & 15) * 4;
     constexpr int AP = 2 * MT;  // A staging passes of 32 rows
     float4 a_regs[KQ][AP], b_regs[KQ][2];
     // this thread's source rows, kept in registers: re-reading them from LDS every tile put a wait-for-LDS and a
@@ -259,27 +265,68 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
     const int lk = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
     const int li = lane & 31;   // row (A) / column (B) inside the 32x32 wave tile
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile((t + 1) * BK);  // in flight under the MFMAs below
+    auto multiply = [&](const float* A, const float* B) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float b = Bs[(kk + lk) * LDBX + wn + li];
+            const float b = B[(kk + lk) * LDBX + wn + li];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float a = As[(kk + lk) * LDA + wm + mt * 32 + li];
+                const float a = A[(kk + lk) * LDA + wm + mt * 32 + li];
                 // the K output of the contiguous layout is stored transposed: swap operands so
                 // that the sequence index lands on the lane (coalesced kt_cache stores)
                 if (transposed_out) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[mt], 0, 0, 0);
                 else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
             }
         }
+    };
+    if constexpr (!SPLIT) {
+        load_tile(0);
+        store_tile();
         __syncthreads();
-        if (t + 1 < nk) {
-            store_tile();
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) load_tile((t + 1) * BK);  // in flight under the MFMAs below
+            multiply(As, Bs);
             __syncthreads();
+            if (t + 1 < nk) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    } else {
+        // One wave doing everything in turn (issue loads, wait, write LDS, read fragments, multiply) is overlapped only by
+        // the other waves of its SIMD; with about one workgroup per CU (logits of 1024 rows, prefill of a few hundred
+        // tokens: 256 tiles of 64 x 64) nothing overlaps and the matrix pipe idles half the time.  Here four waves only load
+        // (two tiles in flight in their registers) and four only multiply, one barrier per k step -- the structure of
+        // gemm_bf16_split_kernel.  Same MFMA chain per output element: bit-identical results.
+        float* As1 = As + BK * LDA;
+        float* Bs1 = Bs + BK * LDBX;
+        if (is_loader) {
+            float4 a2[AP], b2[2];
+            load_slab(0, a_regs[0], b_regs[0]);
+            if (1 < nk) load_slab(BK, a2, b2);
+            store_slab(As, Bs, a_regs[0], b_regs[0]);
+            if (2 < nk) load_slab(2 * BK, a_regs[0], b_regs[0]);
+            __syncthreads();  // tile 0 is in buffer 0
+            for (int t = 0; t < nk; t += 2) {
+                if (t + 1 < nk) store_slab(As1, Bs1, a2, b2);                       // tile t + 1
+                if (t + 3 < nk) load_slab((t + 3) * BK, a2, b2);
+                __syncthreads();
+                if (t + 1 < nk) {
+                    if (t + 2 < nk) store_slab(As, Bs, a_regs[0], b_regs[0]);      // tile t + 2
+                    if (t + 4 < nk) load_slab((t + 4) * BK, a_regs[0], b_regs[0]);
+                    __syncthreads();
+                }
+            }
+        } else {
+            __syncthreads();  // tile 0 is in buffer 0
+            for (int t = 0; t < nk; t += 2) {
+                multiply(As, Bs);
+                __syncthreads();
+                if (t + 1 < nk) {
+                    multiply(As1, Bs1);
+                    __syncthreads();
+                }
+            }
         }
     }
 
@@ -294,6 +341,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         const int n = n0 + wn + li;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (is_loader) break;  // (wave-uniform: the loader waves only meet the barrier below)
             // a score takes part only if it beats -FLT_MAX, as in decoder_argmax_kernel (NaN and -inf never win)
             float v[16];
             int ix[16];
@@ -323,7 +371,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
             }
         }
         __syncthreads();
-        if (tid < BM && m0 + tid < g.M) {
+        if (!is_loader && tid < BM && m0 + tid < g.M) {
             float v = best_v[tid * 2];
             int i = best_i[tid * 2];
             argmax_take(v, i, best_v[tid * 2 + 1], best_i[tid * 2 + 1]);
@@ -331,6 +379,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g)
         }
         return;
     }
+    if (is_loader) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -366,6 +415,8 @@ int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxComp
 static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
 void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
 int deep_k_tiles_enabled() { return g_deep_k_tiles; }
+static int g_gemm_split = 1;  // mli_tune "gemm_split": 0 = never the loader / MFMA wave split of the 64-row-tile kernel
+void set_gemm_split(int v) { g_gemm_split = v != 0; }
 static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v < 0 ? 0 : (v > 2 ? 2 : v); }
 bool gemm_use_tall_tiles(int64_t tall_workgroups) { return g_gemm_tall_tiles == 2 || (g_gemm_tall_tiles == 1 && tall_workgroups >= 512); }
@@ -396,6 +447,13 @@ static int launch_gemm(const GemmArgs& g, int rows, int z, bool vec4, hipStream_
     dim3 grid(tiles_x, ceil_div_i(rows, BM), z);
     if (g.compact && (MODE == kNaiveFill || MODE == kPagedFill))
         grid = dim3(tiles_x, ceil_div_i(rows * z, BM), 1);  // flat (new row, token) list: upper bound
+    // a reduction long enough to pipeline: loader waves + MFMA waves (512 threads).  Measured at D = 2048: logits of 1024
+    // rows 61 -> 52 us, prefill of 128 / 256 / 512 / 4096 prompt tokens 60 -> 49 / 63 -> 52 / 96 -> 86 / 593 -> 588 us,
+    // config 4 logits (K = 512) 21.4 -> 19.5 us: never slower
+    if (vec4 && g_gemm_split && g.K >= 256) {
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true, false, 1, true>), grid, dim3(2 * kGemmThreads), 0, st, g);
+        return launch_status();
+    }
     if (vec4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, true>), grid, dim3(kGemmThreads), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE, BT, false>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();

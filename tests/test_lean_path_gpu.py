@@ -498,3 +498,44 @@ def test_prefill_contiguous_equals_encoder_then_fill(oracle, mli, dev, seed, B, 
     assert_close(host(x1), x0, thr=0, what="inp_embedding vs oracle")
     assert_close(host(kt1), kt0, what="kt_cache vs oracle")
     assert_close(host(v1), v0, what="v_cache vs oracle")
+
+
+# ---- the fp32 GEMM as loader waves + MFMA waves ---------------------------------------------------------------------
+@pytest.mark.parametrize("seed,B,S,D,V", [(181, 70, 64, 256, 300), (182, 33, 48, 516, 1024), (183, 130, 32, 1024, 96)])
+def test_fp32_gemm_wave_split_is_bit_identical(oracle, mli, dev, seed, B, S, D, V):
+    """mli_tune("gemm_split"): the 64-row-tile fp32 GEMM as 512-thread workgroups (four waves load, four multiply) against
+    one wave doing both -- prefill (with and without the encoder prologue), decode projection, logits with the argmax
+    epilogue and materialised logits: every output bit for bit (same MFMA chain per element)."""
+    from min_llm_inference_amd import ops
+    rng = np.random.default_rng(seed)
+    res = []
+    try:
+        assert mli.mli_tune(b"gemm_panel", 0) == 0   # keep the small shapes on the tiled kernel
+        for split in (1, 0):
+            assert mli.mli_tune(b"gemm_split", split) == 0
+            c, d = _prepare(oracle, dev, seed, B, S, D, conditioned=True, zero_every=6)
+            ops.launch_fill_new_k_v_cache_paged_attention(d["page_table"], d["new_batch_idx"], d["lengths"], d["wk"], d["wv"],
+                                                          c["n_new"], S)
+            ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"],
+                                                        d["q_output"], S)
+            g = torch.Generator(device=dev); g.manual_seed(seed)
+            emb = torch.rand(V, D, device=dev, generator=g) * 2 - 1
+            wpe = torch.rand(S, D, device=dev, generator=g) * 2 - 1
+            attn = torch.rand(B, D, device=dev, generator=g) * 2 - 1
+            score = torch.zeros(B, V, device=dev)
+            lengths = d["lengths"].clone()
+            toks = torch.full((B, 1), -5, dtype=torch.int32, device=dev)
+            ops.launch_paged_attention_decoder_multi_rounds(attn, emb, score, wpe, d["page_table"], lengths, toks, 0)
+            lengths2 = d["lengths"].clone()
+            toks2 = torch.full((B, 1), -5, dtype=torch.int32, device=dev)
+            ops.paged_decoder_fused(attn, emb, wpe, d["page_table"], lengths2, toks2, 0, False)
+            inp = torch.randint(0, V, (B, S), dtype=torch.int32, device=dev, generator=g)
+            ops.paged_prefill(emb, wpe, inp, d["page_table"], d["lengths"], d["new_batch_idx"], d["wk"], d["wv"], c["n_new"])
+            res.append({k: host(v) for k, v in (("pool", d["pool"]), ("q", d["q_output"]), ("score", score), ("toks", toks),
+                                                ("toks_fused", toks2), ("lengths", lengths))})
+    finally:
+        mli.mli_tune(b"gemm_split", 1)
+        mli.mli_tune(b"gemm_panel", 1)
+    for k in res[0]:
+        assert_equal(res[0][k], res[1][k], what=k)
+    assert_equal(res[0]["toks"], res[0]["toks_fused"], what="fused head vs materialising head")
