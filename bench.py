@@ -369,7 +369,7 @@ def gemm_report(wl, lengths, times):
             "unit": "TFLOP/s", "frac": tf / peak,
             "note": (f"{flops / 1e9:.1f} GFLOP per launch at B={wl.B}, D={wl.D}" +
                      (": latency-bound, 2 % of the step; the same kernels at D=2048 (bench.py --workload e1) reach "
-                      "118 TFLOP/s fp32 / 551 TFLOP/s bf16 (DESIGN.md 3.5)" if wl.D <= 512 else ""))}
+                      "110-145 TFLOP/s fp32 / 650 TFLOP/s bf16 (DESIGN.md 3.5)" if wl.D <= 512 else ""))}
 
 
 def large_gemm_report(dev):
