@@ -374,8 +374,9 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      fuse when n_batch * n_sequence <= 2^20 (launch-bound steps)
  *   "fill_compact"     1 (default) = the prefill GEMM runs over the flat list of (new row, token) pairs, 0 = one tile
  *                      grid per new row (the reference's decomposition); bit-identical results
- *   "latest_compact"   1 (default) = the decode projection multiplies only the non-empty batch rows, 0 = all rows
- *                      (zeros for the empty ones); bit-identical results
+ *   "latest_compact"   1 (default) = the decode projection multiplies a device-built list of the non-empty batch rows where
+ *                      the reduction is >= 1024 long (building the list costs every workgroup ~2 us), 2 = wherever
+ *                      possible, 0 = all rows (empty ones as zeros); identical results
  *   "gemm_deep_k"      1 (default) = the bf16 GEMM stages 128 k per tile for latency-bound shapes, 0 = 32 everywhere
  *   "naive_scan_fused" 1 (default) = mli_self_attention_lean runs the single-launch contiguous scan, 0 = it returns
  *                      MLI_ERR_BAD_ARG (callers fall back to mli_inference_self_attention)

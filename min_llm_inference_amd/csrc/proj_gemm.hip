@@ -408,9 +408,17 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int g_fill_compact = 1;  // mli_tune "fill_compact": 0 = one tile grid per new row (the reference's decomposition)
 void set_fill_compact(int v) { g_fill_compact = v != 0; }
 int fill_compact(int n_new) { return g_fill_compact && n_new <= kMaxCompactRows ? 1 : 0; }
-static int g_latest_compact = 1;  // mli_tune "latest_compact": 0 = the decode projection multiplies empty rows as zeros
-void set_latest_compact(int v) { g_latest_compact = v != 0; }
-int latest_compact(int n_batch) { return g_latest_compact && n_batch <= kMaxCompactRows ? 1 : 0; }
+// mli_tune "latest_compact": 0 = the decode projection multiplies empty rows as zeros, 1 (default) = it multiplies a
+// device-built list of the non-empty rows where that can pay, 2 = wherever possible (tests).  Every workgroup rebuilds the
+// list (a prefix sum over the batch rows): ~1.8 us of prologue -- config 4's projection (emb_dim 512) takes 9.4 us without
+// it and 11.2 with it, and could save 3-4 us at best from a batch that is 40 % empty slots; at emb_dim 2048 (222 us) the same
+// batch saves 90 us.  So: only for reductions of 1024 and more.
+static int g_latest_compact = 1;
+void set_latest_compact(int v) { g_latest_compact = v < 0 ? 0 : (v > 2 ? 2 : v); }
+int latest_compact(int n_batch, int k_dim) {
+    if (g_latest_compact == 0 || n_batch > kMaxCompactRows) return 0;
+    return g_latest_compact == 2 || k_dim >= 1024 ? 1 : 0;
+}
 
 static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
 void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
@@ -468,7 +476,7 @@ int launch_latest_naive(const float* inp, const int* lengths, const float* wk, c
     g.M = B; g.N = Dout; g.K = Din;
     g.inp_embedding = inp; g.kt_cache = kt; g.v_cache = v; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
-    g.compact = latest_compact(B);
+    g.compact = latest_compact(B, Din);
     const bool vec4 = Din % 4 == 0 && Dout % 4 == 0 && aligned16(inp) && aligned16(wk) && aligned16(wq) && aligned16(wv);
     return launch_gemm<kNaiveLatest, false>(g, B, 1, vec4, st);
 }
@@ -507,7 +515,7 @@ int launch_latest_paged(float* const* page_table, const int* lengths, const floa
     g.M = B; g.N = D; g.K = D;
     g.page_table = page_table; g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
-    g.compact = latest_compact(B);
+    g.compact = latest_compact(B, D);
     const bool vec4 = aligned16(wk) && aligned16(wq) && aligned16(wv);
     return launch_gemm<kPagedLatest, false>(g, B, 1, vec4, st);
 }
@@ -554,7 +562,7 @@ int launch_latest_paged_bf16(uint16_t* const* page_table, const int* lengths, co
     g.M = B; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
-    g.compact = latest_compact(B);
+    g.compact = latest_compact(B, D);
     dim3 grid(ceil_div_i(D, BN) * 3, ceil_div_i(B, BM), 1);
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<kPagedLatest, false, true, true>), grid, dim3(kGemmThreads), 0, st, g);
     return launch_status();

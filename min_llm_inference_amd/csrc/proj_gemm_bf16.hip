@@ -24,7 +24,7 @@ constexpr int kLdbBytes = HN * 2 + 64;   // 192
 constexpr int kHThreads = 256;
 
 int fill_compact(int n_new);  // proj_gemm.hip
-int latest_compact(int n_batch);
+int latest_compact(int n_batch, int k_dim);
 bool gemm_use_tall_tiles(int64_t tall_workgroups);
 int deep_k_tiles_enabled();
 
@@ -460,7 +460,7 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.M = B; g.N = D; g.K = D;
     g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
     g.B = B; g.S = S;
-    g.compact = latest_compact(B);
+    g.compact = latest_compact(B, D);
     const int tiles_x = ceil_div_i(D, HN) * 3;
     if (g_bf16_split && D % kSpN == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
         static std::atomic<unsigned long long> opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device

@@ -89,12 +89,14 @@ def test_latest_live_row_list_equals_dense_rows(oracle, mli, dev, seed, B, S, D,
     (mli_tune latest_compact = 0): bit-identical pages and q_output, empty rows' q_output untouched either way."""
     from min_llm_inference_amd import ops
     got = []
-    for compact in (1, 0):
+    for compact in (2, 0):   # 2 = the live-row list whatever the reduction length (by default only from emb_dim 1024 on)
         assert mli.mli_tune(b"latest_compact", compact) == 0
+        assert mli.mli_tune(b"gemm_panel", 0) == 0   # (the panel kernel never builds the list)
         c, d = _prepare(oracle, dev, seed, B, S, D, zero_every=zero_every)
         ops.launch_get_latest_k_q_v_paged_attention(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["q_output"], S)
         got.append((host(d["pool"]), host(d["q_output"])))
     mli.mli_tune(b"latest_compact", 1)
+    mli.mli_tune(b"gemm_panel", 1)
     assert_equal(got[0][0], got[1][0], what="page pool: live-row list vs dense rows")
     assert_equal(got[0][1], got[1][1], what="q_output: live-row list vs dense rows")
     empty = c["lengths"] == 0
