@@ -19,7 +19,12 @@
 //   emb_table panel before they wait and start as soon as THEIR 32 rows are merged: the head overlaps the scan's drain.
 // * Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): producers store write-through (sc1), every storing
 //   wave drains (s_waitcnt vmcnt(0)), barrier, one lane adds to the counter at agent scope; consumers: one lane polls
-//   (relaxed sc1 loads, s_sleep), agent acquire, s_waitcnt vmcnt(0), barrier, then plain loads.
+//   (relaxed sc1 loads, s_sleep), barrier, then loads.  No agent acquire (2-6 us per workgroup under load) where the
+//   handed-off bytes are FIRST TOUCHED after the hand-off -- sf_wait's comment says why that is enough; the rows' chunk
+//   merges (row_publish_merge), whose partial rows ARE re-read from launch to launch, keep theirs.
+// * MEASURED SLOWER than the separate launches (config 3: 72 vs 67 us) and therefore opt-in
+//   (mli_tune "step_fused"): the launches were already back to back, and every role is a chain of dependent memory round
+//   trips that a hand-off does not shorten.
 // * lengths[b] is rewritten by the block's finalizer while scan items of OTHER tickets may not have read it yet (an item
 //   beyond a row's length is empty, but it has to read the length to know): every scan item counts in len_read[block]
 //   once the length is in its register, and the finalizer waits for that count first.
