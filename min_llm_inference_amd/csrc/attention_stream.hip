@@ -479,7 +479,7 @@ void set_scan_stream(int v) { g_scan_stream = v != 0; }
 // what saturates HBM, so the workgroups that are still streaming simply speed up when others finish.
 static int g_stream_dyn_pct = 4;
 static int g_stream_granule = 64;
-void set_stream_dyn_pct(int v) { g_stream_dyn_pct = v < 0 ? 0 : (v > 12 ? 12 : v); }   // (the slot bound above assumes <= 12)
+void set_stream_dyn_pct(int v) { g_stream_dyn_pct = v < 0 ? 0 : (v > 60 ? 60 : v); }
 void set_stream_granule(int v) { g_stream_granule = v < 16 ? 16 : (v > 256 ? 256 : v); }
 static int g_scan_stream_min = 1 << 21;   // mli_tune "scan_stream_min_tokens": n_batch * n_sequence from which it is used
 void set_scan_stream_min(int v) { g_scan_stream_min = v < 0 ? 0 : v; }
