@@ -59,9 +59,12 @@ void allocate_memory_block(MemoryBlockManager&, PagedAttentionsManager&, BatchId
 
 // Returns the pages of finished rows, grows rows that are about to cross a page boundary, and preempts
 // rows from the tail of the admission list (back to the head of the queue) when the pool is empty.
+// last_row_short (extension, for the pipelined loop's look-ahead): when given, the ONLY row left in flight is not
+// preempted when the pool cannot grow it -- *last_row_short is set instead and the row keeps its pages, so the caller
+// can first learn whether the row needs the page at all (it may have finished in the forward that is still running).
 void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager&, MemoryBlockManager&, ProcessingStorage&,
                                               ItemStorage&, const std::vector<int>& finished_indices,
-                                              int n_forward_rounds);
+                                              int n_forward_rounds, bool* last_row_short = nullptr);
 
 // The host-only half of the paged insert: admission decisions, page hand-out, host mirrors (inp rows, lengths,
 // new_idx[0 .. slots.size())) -- no device traffic.  insert_new_items = this + the uploads; the pipelined engine

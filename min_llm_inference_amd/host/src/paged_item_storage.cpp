@@ -91,7 +91,9 @@ void allocate_memory_block(MemoryBlockManager& pool, PagedAttentionsManager& pag
 
 void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager& pages, MemoryBlockManager& pool,
                                               ProcessingStorage& processing_storage, ItemStorage& item_storage,
-                                              const std::vector<int>& finished_indices, int n_forward_rounds) {
+                                              const std::vector<int>& finished_indices, int n_forward_rounds,
+                                              bool* last_row_short) {
+    if (last_row_short != nullptr) *last_row_short = false;
     // a row needs at most one more page per iteration
     assert(n_forward_rounds > 0 && n_forward_rounds <= PAGE_BLOCK_SIZE);
     std::list<BatchIdMemoryBlocksPair>& rows = pages.get_used_block_list();
@@ -132,6 +134,10 @@ void allocate_or_free_memory_blocks_if_needed(PagedAttentionsManager& pages, Mem
         if (pool.free_blocks_size() > 0) {
             allocate_memory_block(pool, pages, *it);  // re-checked on the next pass of the loop
         } else if (std::next(it) == rows.end()) {
+            if (last_row_short != nullptr && it == rows.begin()) {  // the only row left: the caller decides
+                *last_row_short = true;
+                break;
+            }
             processing_storage.move_to_new(it->first, item_storage);
             pool.return_free_blocks(std::move(it->second));
             it = rows.erase(it);

@@ -95,54 +95,8 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
         return static_cast<int>(adm.slots.size());
     };
 
-    long long step = 0;
-    int n_new = admit(0);
-    {
-        Range r("forward");
-        forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
-    }
-    while (true) {
-        // A. result(step) starts travelling as soon as forward(step) is done
-        result_host.copy_range_from_async(result_device, 0, n_batch_size * n_rounds);
-        mli::mem::record_marker(marker.m);
-
-        // B. pages for forward(step + 1): every in-flight row has up to R tokens in flight (one per round of
-        //    forward(step)) and forward(step + 1) appends up to R more, so it needs room for tokens + 2 R positions
-        //    (the reference's rule with the in-flight tokens counted); a dry pool preempts from the tail of the
-        //    admission list, and the victim's device length is zeroed before forward(step + 1)
-        {
-            Range r("allocate_or_free_memory_blocks_if_needed");
-            const size_t in_flight_before = processing_storage.size();
-            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2 * R);
-            if (in_flight_before > 0 && processing_storage.size() == 0) {
-                // Every row was preempted, the last one by itself: with the whole pool to itself it still has no room
-                // for its next token.  Re-admitting it (its in-flight token is dropped, so it would fit again) and
-                // preempting it here again would repeat forever; the sequential loops report the same state as an
-                // error after their admission refuses the row (inferencer.cpp: throw_if_stuck).
-                mli::runtime::synchronize();
-                throw std::runtime_error("paged engine: the page pool is too small for the next queued item");
-            }
-            idx.clear();
-            val.clear();
-            for (int b = 0; b < B; ++b) {
-                if (first_step[b] >= 0 && !processing_storage.batch_id_processing(b)) {  // preempted just now
-                    first_step[b] = -1;
-                    lengths_host.data()[b] = 0;
-                    idx.push_back(b);
-                    val.push_back(0);
-                }
-            }
-            if (!idx.empty()) lengths_device.scatter_from_host(idx.data(), val.data(), idx.size());
-        }
-
-        // C. + D. admission into the slots known to be free, then the next forward
-        n_new = admit(step + 1);
-        {
-            Range r("forward");
-            forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
-        }
-
-        // E. result(step)
+    // E. result(step): wait for its copy, append the tokens, retire finished rows, hand their pages back
+    auto process_result = [&](long long step) {
         std::vector<int> finished;
         {
             Range r("process_decoder_result");
@@ -168,13 +122,76 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
             }
             get_global_throughput_counter().add_record_if_recording(appended);
         }
-        // pages of finished rows go back; with R rounds and the tokens just appended this asks for no more than B
-        // already provided, so nothing grows here
-        if (!finished.empty())
-            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/R);
+        return finished;
+    };
+    // rows the bookkeeping has just preempted: their device length is zeroed before the next forward
+    auto zero_preempted_rows = [&]() {
+        idx.clear();
+        val.clear();
+        for (int b = 0; b < B; ++b) {
+            if (first_step[b] >= 0 && !processing_storage.batch_id_processing(b)) {
+                first_step[b] = -1;
+                lengths_host.data()[b] = 0;
+                idx.push_back(b);
+                val.push_back(0);
+            }
+        }
+        if (!idx.empty()) lengths_device.scatter_from_host(idx.data(), val.data(), idx.size());
+    };
+
+    long long step = 0;
+    int n_new = admit(0);
+    {
+        Range r("forward");
+        forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
+    }
+    while (true) {
+        // A. result(step) starts travelling as soon as forward(step) is done
+        result_host.copy_range_from_async(result_device, 0, n_batch_size * n_rounds);
+        mli::mem::record_marker(marker.m);
+
+        // B. pages for forward(step + 1): every in-flight row has up to R tokens in flight (one per round of
+        //    forward(step)) and forward(step + 1) appends up to R more, so it needs room for tokens + 2 R positions
+        //    (the reference's rule with the in-flight tokens counted); a dry pool preempts from the tail of the
+        //    admission list, and the victim's device length is zeroed before forward(step + 1).
+        //    The look-ahead must not cost the LAST row its place: it may be finishing in forward(step) (EOF, or its
+        //    last token landing on a page boundary), in which case it never needs the page -- the sequential loop, which
+        //    asks for tokens + R after the result, completes such a workload (pools smaller than the table width).
+        //    So when the only row in flight cannot get its look-ahead page, this iteration runs in the reference's
+        //    order: result(step) first, then the sequential rule decides (and preempts, if the row really needs it).
+        bool result_done = false;
+        {
+            Range r("allocate_or_free_memory_blocks_if_needed");
+            bool last_row_short = false;
+            allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, {}, /*rounds=*/2 * R,
+                                                     &last_row_short);
+            if (last_row_short) {
+                const std::vector<int> finished = process_result(step);
+                allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/R);
+                result_done = true;
+            }
+            zero_preempted_rows();
+        }
+
+        // C. + D. admission into the slots known to be free, then the next forward
+        //    (nothing in flight, nothing admitted, items queued: admit() reports "pool too small", as the sequential
+        //    loops do after their admission refuses the row -- inferencer.cpp: throw_if_stuck)
+        n_new = admit(step + 1);
+        {
+            Range r("forward");
+            forward(inp_device, lengths_device, new_idx_device, result_device, n_new);
+        }
+
+        // E. result(step), unless B already needed it
+        if (!result_done) {
+            const std::vector<int> finished = process_result(step);
+            // pages of finished rows go back; with R rounds and the tokens just appended this asks for no more than B
+            // already provided, so nothing grows here
+            if (!finished.empty())
+                allocate_or_free_memory_blocks_if_needed(pages, pool, processing_storage, item_storage, finished, /*rounds=*/R);
+        }
         ++step;
         if (is_done(item_storage, processing_storage)) break;
-
     }
     mli::runtime::synchronize();  // forward(step) is still in flight (every row empty): drain before the tensors go
     return step + 1;

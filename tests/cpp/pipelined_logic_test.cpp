@@ -107,9 +107,68 @@ static long long run_sequential(World& w, FakeModel& model, size_t B, size_t S, 
         std::vector<int> finished = process_decoder_result(res_d, res_h, w.items, w.processing, static_cast<int>(S));
         allocate_or_free_memory_blocks_if_needed(w.pages, w.pool, w.processing, w.items, finished, R);
         fresh = insert_new_items(inp_d, inp_h, len_d, len_h, idx_d, idx_h, w.items, w.processing, w.pool, w.pages, R);
+        if (w.processing.size() == 0 && w.items.new_count() > 0) return -1;   // inferencer.cpp: throw_if_stuck
         if (++steps > 1000000) break;
     }
     return steps;
+}
+
+// Pools SMALLER than the page-table width: the look-ahead of the pipelined loop (tokens + 2 R positions, asked
+// for before result(step) is known) must not cost the last row in flight its place when the row is in fact finishing in
+// forward(step).  Whatever the sequential loop does with the workload -- finish it, or report the pool as too small --
+// the pipelined loop must do too, with the same tokens.
+static void run_tight_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_items, int max_prompt, int eof_bias, int rounds) {
+    std::mt19937 rng(seed);
+    std::vector<IdTokensPair> items;
+    for (int i = 0; i < n_items; ++i) {
+        std::vector<int> toks(1 + rng() % max_prompt);
+        for (int& t : toks) t = static_cast<int>(rng() % EOF_TOKEN_ID);
+        items.emplace_back(i, toks);
+    }
+    std::map<int, std::vector<int>> seq, pip;
+    long long seq_steps;
+    {
+        World w(B, S, n_blocks);
+        for (const auto& it : items) w.items.add_new_item(IdTokensPair(it));
+        FakeModel model{(int)B, (int)S, eof_bias, std::vector<uint64_t>(B, 0), &w.pages};
+        model.rounds = rounds;
+        get_global_throughput_counter().reset();
+        get_global_throughput_counter().start_record();
+        seq_steps = run_sequential(w, model, B, S, rounds);
+        seq = collect(w.items);
+        CHECK(model.missing_pages == 0);
+    }
+    bool threw = false;
+    int missing = 0;
+    {
+        World w(B, S, n_blocks);
+        for (const auto& it : items) w.items.add_new_item(IdTokensPair(it));
+        FakeModel model{(int)B, (int)S, eof_bias, std::vector<uint64_t>(B, 0), &w.pages};
+        model.rounds = rounds;
+        get_global_throughput_counter().reset();
+        try {
+            run_paged_engine_pipelined(w.items, w.processing, w.pool, w.pages, B, S,
+                                       [&](const TensorInt& inp, TensorInt& len, const TensorInt& idx, TensorInt& res, int n_new) {
+                                           if (model.launches > 200000) throw std::logic_error("no progress");
+                                           model.forward(inp, len, idx, res, n_new);
+                                       }, rounds);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        pip = collect(w.items);
+        missing = model.missing_pages;
+    }
+    CHECK(missing == 0);
+    CHECK(threw == (seq_steps < 0));
+    int different = 0;
+    if (seq_steps >= 0) {
+        CHECK((int)pip.size() == n_items);
+        for (const auto& kv : seq) different += pip[kv.first] != kv.second;
+        CHECK(different == 0);
+    }
+    std::printf("%s tight seed %u: B=%zu S=%zu blocks=%d (width %zu) items=%d eof=%d%% rounds=%d  sequential %s, pipelined %s\n",
+                missing == 0 && threw == (seq_steps < 0) && different == 0 ? "[ OK ]" : "[FAIL]", seed, B, S, n_blocks,
+                S / PAGE_BLOCK_SIZE, n_items, eof_bias, rounds, seq_steps < 0 ? "stuck" : "finished", threw ? "reported" : "finished");
 }
 
 static void run_case(unsigned seed, size_t B, size_t S, int n_blocks, int n_items, int max_prompt, int eof_bias,
@@ -190,6 +249,79 @@ int main() {
         const int max_prompt = 1 + rng() % (S - 2 - rounds);
         const int eof_bias = (seed % 3 == 0) ? 0 : static_cast<int>(rng() % 12);
         run_case(2000 + seed, B, S, n_blocks, n_items, max_prompt, eof_bias, rounds);
+    }
+    {
+        int finished_cases = 0;
+        for (unsigned seed = 0; seed < 60; ++seed) {
+            const size_t B = 1 + rng() % 6;
+            const size_t S = 16 * (6 + rng() % 11);          // width 6 .. 16
+            const int width = static_cast<int>(S / 16);
+            const int n_blocks = DEFAULT_INIT_NUM_BLOCKS + rng() % (width - DEFAULT_INIT_NUM_BLOCKS);   // [4, width)
+            const int rounds = (seed % 3 == 0) ? 1 : 2 + rng() % 7;
+            const int n_items = 1 + rng() % 8;
+            const int room = n_blocks * 16 - rounds - 2;
+            const int max_prompt = 1 + rng() % std::max(1, std::min<int>(room, S - 2 - rounds) / 2);
+            const int eof_bias = 2 + rng() % 10;            // rows end on EOF somewhere inside the pool, or outgrow it
+            const int before = g_failures;
+            run_tight_case(3000 + seed, B, S, n_blocks, n_items, max_prompt, eof_bias, rounds);
+            finished_cases += g_failures == before;
+        }
+        CHECK(finished_cases > 0);
+    }
+    {   // the row's last token lands exactly on a page boundary and is EOF: one row, a pool of exactly the pages it uses
+        for (int rounds : {1, 2, 4, 8}) {
+            World w(1, 160, DEFAULT_INIT_NUM_BLOCKS);
+            // find a prompt whose greedy continuation under the fake model emits EOF as token number 64 (4 pages full)
+            bool found = false;
+            std::vector<int> prompt;
+            for (int first = 0; first < 200000 && !found; ++first) {
+                FakeModel probe{1, 160, 3, std::vector<uint64_t>(1, 0), nullptr};
+                uint64_t hh = FakeModel::mix(0x1234, (uint64_t)(first % EOF_TOKEN_ID));
+                hh = FakeModel::mix(hh, (uint64_t)(first / EOF_TOKEN_ID));
+                int n = 2;
+                while (n < 64) {
+                    const int tok = probe.token_of(hh);
+                    if (tok == EOF_TOKEN_ID) break;
+                    hh = FakeModel::mix(hh, (uint64_t)tok);
+                    ++n;
+                }
+                if (n == 63 && probe.token_of(hh) == EOF_TOKEN_ID) {
+                    found = true;
+                    prompt = {first % EOF_TOKEN_ID, first / EOF_TOKEN_ID};
+                    w.items.add_new_item(IdTokensPair(0, prompt));
+                }
+            }
+            CHECK(found);
+            if (!found) continue;
+            // what the reference's loop order does with it: with R rounds it asks for tokens + R positions after every
+            // result, so it completes the row only where 62 % R == 0 (the row's last forward then starts at 64 - R tokens)
+            long long seq_steps;
+            {
+                World ws(1, 160, DEFAULT_INIT_NUM_BLOCKS);
+                ws.items.add_new_item(IdTokensPair(0, prompt));
+                FakeModel ms{1, 160, 3, std::vector<uint64_t>(1, 0), &ws.pages};
+                ms.rounds = rounds;
+                seq_steps = run_sequential(ws, ms, 1, 160, rounds);
+            }
+            FakeModel model{1, 160, 3, std::vector<uint64_t>(1, 0), &w.pages};
+            model.rounds = rounds;
+            bool threw = false;
+            try {
+                run_paged_engine_pipelined(w.items, w.processing, w.pool, w.pages, 1, 160,
+                                           [&](const TensorInt& inp, TensorInt& len, const TensorInt& idx, TensorInt& res, int n_new) {
+                                               model.forward(inp, len, idx, res, n_new);
+                                           }, rounds);
+            } catch (const std::runtime_error&) {
+                threw = true;
+            }
+            CHECK(threw == (seq_steps < 0));
+            if (rounds <= 2) CHECK(!threw);
+            CHECK(model.missing_pages == 0);
+            if (!threw) CHECK(w.items.get_finished_items().size() == 1 && w.items.get_finished_items().front().second.size() == 64);
+            std::printf("%s EOF as the 64th token of a row in a pool of 4 pages, %d round(s): sequential %s, pipelined %s\n",
+                        threw == (seq_steps < 0) ? "[ OK ]" : "[FAIL]", rounds, seq_steps < 0 ? "stuck" : "finished",
+                        threw ? "reported" : "finished");
+        }
     }
     {   // a pool that cannot hold even one row: an error, not an endless loop
         World w(4, 64, DEFAULT_INIT_NUM_BLOCKS - 1);

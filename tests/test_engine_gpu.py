@@ -243,6 +243,41 @@ def test_pipelined_engine_multi_round_random_configurations(oracle, mli, dev, se
                 (name, item_id, B, S, D, n_blocks, rounds)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_pipelined_engine_pools_smaller_than_the_table_width(mli, dev, seed):
+    """n_blocks in [4, width) and several forward rounds.  The pipelined loop asks for tokens + 2 R positions
+    before result(step) is known; when the only row in flight cannot get that look-ahead page it must not preempt itself
+    (the row may be emitting EOF in the forward that is still running) but take the reference's order for that
+    iteration.  Whatever the sequential loop does with the workload -- finish it, or report the pool as too small -- the
+    pipelined loop must do too, with the same tokens.  (EOF row scaled x3: rows end on EOF after ~10 tokens.)"""
+    from min_llm_inference_amd import MliError, engine as eng
+    rng = np.random.default_rng(8000 + seed)
+    B = int(rng.integers(1, 5))
+    S = 16 * int(rng.integers(6, 13))
+    width = S // 16
+    n_blocks = int(rng.integers(4, width))
+    rounds = [1, 2, 3, 4, 6, 8, 2, 5][seed]
+    D, V = 64, 1024
+    model = make_model(8100 + seed, V, S, D)
+    model["emb_table"][1023] *= 3.0
+    items = make_items(8200 + seed, int(rng.integers(1, 9)), 1, max(1, min(n_blocks * 16 - 2 * rounds - 2, 40)))
+
+    def run(pipelined):
+        try:
+            return _run(eng.PAGED, model, items, B, S, n_blocks=n_blocks, rounds=rounds, pipelined=pipelined)
+        except MliError as e:
+            assert "too small" in str(e)
+            return None, None
+
+    st_seq, seq = run(False)
+    st_pip, pip = run(True)
+    assert (st_seq is None) == (st_pip is None), (B, S, n_blocks, rounds, "sequential " + ("reported" if st_seq is None else "finished"))
+    if st_seq is not None:
+        assert st_seq.finished == len(items) and st_pip.finished == len(items)
+        for item_id, _ in items:
+            assert len(pip[item_id]) == len(seq[item_id]) and (pip[item_id] == seq[item_id]).all(), (item_id, B, S, n_blocks, rounds)
+
+
 @pytest.mark.parametrize("kind_name,rounds,pipelined", [("PAGED", 1, True), ("PAGED_GEMM", 3, True), ("PAGED", 2, False)])
 def test_step_graph_replay_gives_the_same_tokens(oracle, mli, dev, kind_name, rounds, pipelined):
     """Decode forwards replayed from a hipGraph (recorded on the engine's private stream at the second pure decode
