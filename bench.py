@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+# dmabuf IPC is the only IPC flavour the host driver supports: RCCL / cross-process device memory need it.  Set in the
+# rank itself, before anything initialises the GPU runtime -- ranks started by an outer torch.distributed.run never pass
+# through self_launch() below.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
@@ -40,6 +45,7 @@ WORKLOADS = {
     "e1": ("paged", 1024, 2048, 128),
 }
 N_VOCAB = 1024
+ELEM_NAMES = {"f32": "fp32", "bf16": "bf16 pages and weights", "fp8": "fp8 (OCP e4m3) pages, bf16 weights"}
 SCAN_LEAN = ("fused_decode_scan, lean (q.K^T + online softmax + softmax.V + in-kernel merge, one visit per page; "
              "fused_decode_stream_kernel = equal page shares where the batch fills the chip, else fused_decode_scan_kernel)")
 SCAN_FULL = "fused_decode_scan, materialising (raw scores written; merged by fused_decode_combine)"
@@ -289,14 +295,17 @@ def time_kernel(fn, reps, batch=1):
     return e0.elapsed_time(e1) / (n * per)
 
 
-def measure_copy_gbs(dev):
-    n = 1 << 28  # 1 GiB of floats in, 1 GiB out
+def measure_read_gbs(dev):
+    """The box's streaming-read rate (mli_stream_read: every wave streams its own contiguous region with 16-byte
+    non-temporal lane loads, 16 KiB in flight) -- the ceiling a read-only scan can be held against.  (A device COPY, which
+    earlier rounds reported here, is not a ceiling for a read stream: its writes cost more than its reads.)"""
+    n = 1 << 30  # 4 GiB of floats
     a = torch.empty(n, device=dev)
-    b = torch.empty(n, device=dev)
     a.uniform_()
-    ms = time_kernel(lambda: ops.stream_copy(a, b), 10)
-    del a, b
-    return 2 * n * 4 / (ms * 1e-3) / 1e9
+    sink = torch.zeros(64, device=dev)
+    ms = time_kernel(lambda: ops.stream_read(a, sink), 10)
+    del a
+    return n * 4 / (ms * 1e-3) / 1e9
 
 
 def cpu_baseline(wl, budget_s=12.0):
@@ -438,39 +447,51 @@ def run_engine_mode(args, rank, world, dev):
     assert B % R == 0
     weights = (emb, u(S, D), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)), u(D, D, scale=1 / np.sqrt(D)))
     items = [(i, rng.integers(0, ops.EOF_TOKEN_ID, size=int(rng.integers(1, 65)))) for i in range(2 * B)]
-    engines = []
-    for r in range(R):  # R engines of B / R slots each share the GPU (private streams, one host thread each)
-        e = eng.Engine(kind, B // R, S, D, V, *weights, n_blocks=n_blocks // R, n_forward_rounds=1, device=dev.index,
-                       reference_length_reset_quirk=args.reference_quirk)
-        if R > 1 or args.step_graphs:
-            e.use_private_stream()
-        if args.pipelined or args.sequential_loop:
-            e.set_pipelined(not args.sequential_loop)   # default: the engine picks the pipelined loop where it applies
-        for i, toks in items[r::R]:
-            e.add_item(i, toks)
-        engines.append(e)
-    if R == 1:
-        st = engines[0].run()
-        assert st.finished == 2 * B
-        return st, (B, S, D, V, n_blocks)
-    import threading
-    stats = [None] * R
-    def drive(r):
-        stats[r] = engines[r].run()
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(R)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    wall = time.perf_counter() - t0
-    assert sum(s.finished for s in stats) == 2 * B
 
-    class Total:  # whole-GPU totals: tokens of all engines over the wall time of the slowest
-        total_tokens = sum(s.total_tokens for s in stats)
-        seconds = max(max(s.seconds for s in stats), wall)
-        iterations = max(s.iterations for s in stats)
-    return Total, (B, S, D, V, n_blocks)
+    def one_run():
+        engines = []
+        for r in range(R):  # R engines of B / R slots each share the GPU (private streams, one host thread each)
+            e = eng.Engine(kind, B // R, S, D, V, *weights, n_blocks=n_blocks // R, n_forward_rounds=1, device=dev.index,
+                           reference_length_reset_quirk=args.reference_quirk)
+            if R > 1 or args.step_graphs:
+                e.use_private_stream()
+            if args.pipelined or args.sequential_loop:
+                e.set_pipelined(not args.sequential_loop)   # default: the engine picks the pipelined loop where it applies
+            for i, toks in items[r::R]:
+                e.add_item(i, toks)
+            engines.append(e)
+        try:
+            if R == 1:
+                st = engines[0].run()
+                assert st.finished == 2 * B
+                return types.SimpleNamespace(total_tokens=st.total_tokens, seconds=st.seconds, iterations=st.iterations)
+            import threading
+            stats = [None] * R
+            def drive(r):
+                stats[r] = engines[r].run()
+            threads = [threading.Thread(target=drive, args=(r,)) for r in range(R)]
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            wall = time.perf_counter() - t0
+            assert sum(s.finished for s in stats) == 2 * B
+            # whole-GPU totals: tokens of all engines over the wall time of the slowest
+            return types.SimpleNamespace(total_tokens=sum(s.total_tokens for s in stats),
+                                         seconds=max(max(s.seconds for s in stats), wall),
+                                         iterations=max(s.iterations for s in stats))
+        finally:
+            for e in engines:
+                e.close()
+
+    import types
+    runs = [one_run() for _ in range(max(1, args.engine_repeats))]
+    rates = sorted((r.total_tokens / r.seconds, i) for i, r in enumerate(runs))
+    st = runs[rates[len(rates) // 2][1]]                        # the median run is the one reported
+    st.repeat = {"runs": len(runs), "median": rates[len(rates) // 2][0], "min": rates[0][0], "max": rates[-1][0],
+                 "all": [r.total_tokens / r.seconds for r in runs], "unit": "tokens/s"}
+    return st, (B, S, D, V, n_blocks)
 
 
 def launcher_command(n_ranks, argv, port):
@@ -529,6 +550,10 @@ def main():
     ap.add_argument("--engine-replicas", type=int, default=1,
                     help="engine mode: split the slots over this many engines on the same GPU (private streams, one "
                          "host thread each) so one engine's host bookkeeping overlaps the other's kernels")
+    ap.add_argument("--engine-repeats", type=int, default=5,
+                    help="engine mode: runs of the workload (a fresh engine each, same items); the median run is reported")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="step mode: timed regions of exactly --steps steps each (same state); the median region is `value`")
     ap.add_argument("--engine-shape", action="store_true",
                     help="engine mode: run the --workload shape (e.g. c4) instead of the reference's profiling shape e1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing "
@@ -609,7 +634,7 @@ def main():
                            "vs_baseline_note": "per-GPU value / README.md:79-82 (123284 tok/s, unnamed NVIDIA GPU)",
                            "reference_length_reset_quirk": bool(args.reference_quirk),
                            "layers": "reference launch sequence" if args.reference_launch_sequence else "lean compositions",
-                           "total_tokens": tok.item(), "seconds": sec.item()}}))
+                           "repeat": st.repeat, "total_tokens": tok.item(), "seconds": sec.item()}}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -624,8 +649,10 @@ def main():
         dist.destroy_process_group()
 
 
-def timed_steps(wl, step, steps, warmup, world, dist, gather=None):
-    """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+def timed_steps(wl, step, steps, warmup, world, dist, gather=None, repeats=1):
+    """W untimed steps, then `repeats` timed regions of EXACTLY K steps each, every region bracketed by barrier +
+    synchronize on both sides and started from the same state (the lengths are put back outside the timed region).
+    Returns the list of per-region wall times of this rank (the caller takes the max over ranks per region)."""
     def one():
         if gather is not None:
             # the decoder writes this step's tokens into a buffer whose previous gather has completed; the gather of
@@ -640,22 +667,37 @@ def timed_steps(wl, step, steps, warmup, world, dist, gather=None):
         one()
     if gather is not None:
         gather.wait()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # every row must still be live, otherwise "tokens" would over-count
-    grown = (wl.lengths - wl.lengths0).cpu().numpy()
-    assert (grown == steps + warmup).all(), "a row finished during the timed region"
-    return elapsed
+    regions = []
+    for _ in range(max(1, repeats)):
+        wl.lengths.copy_(wl.lengths0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        if gather is not None:
+            gather.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        regions.append(time.perf_counter() - t0)
+        # every row must still be live, otherwise "tokens" would over-count
+        grown = (wl.lengths - wl.lengths0).cpu().numpy()
+        assert (grown == steps).all(), "a row finished during the timed region"
+    return regions
+
+
+def region_stats(regions, steps):
+    """ms per step of the repeated K-step regions: the median region is the headline, min / max say how far to trust it."""
+    ms = sorted(r / steps * 1e3 for r in regions)
+    return {"regions": len(ms), "median_ms_per_step": ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]),
+            "min_ms_per_step": ms[0], "max_ms_per_step": ms[-1], "all_ms_per_step": [r / steps * 1e3 for r in regions]}
+
+
+def median_region(regions):
+    r = sorted(regions)
+    return r[len(r) // 2] if len(r) % 2 else 0.5 * (r[len(r) // 2 - 1] + r[len(r) // 2])
 
 
 def roofline_report(wl, workload, dtype, lengths_now, ms_per_step, reps, lean=True):
@@ -691,19 +733,24 @@ def roofline_report(wl, workload, dtype, lengths_now, ms_per_step, reps, lean=Tr
     }, times
 
 
-def side_config(name, dtype, dev, steps, warmup):
+def side_config(name, dtype, dev, steps, warmup, repeats, cpu_budget_s=0.0):
     """One of the other BASELINE configurations as a short single-GPU step run (the `configs` block of the line)."""
     cfg_index = sorted(WORKLOADS).index(name) + 1
     wl = Workload(name, dev, 0x5EED0000 + cfg_index * 16, headroom=steps + warmup + 8, dtype=dtype)
     wl.lean_step()
     wl.lengths.copy_(wl.lengths0)
-    elapsed = timed_steps(wl, wl.lean_step, steps, warmup, 1, None)
+    regions = timed_steps(wl, wl.lean_step, steps, warmup, 1, None, repeats=repeats)
+    elapsed = median_region(regions)
     ms = elapsed / steps * 1e3
     roof, _ = roofline_report(wl, name, dtype, wl.lengths.cpu().numpy(), ms, max(20, steps // 2))
     r = {"workload": f"{name}: {wl.layout} KV decode step, {wl.B} rows, emb_dim {wl.D}, max_seq {wl.S}, "
-                     f"{'bf16 pages and weights' if dtype == 'bf16' else 'fp32'}, lean composition",
+                     f"{ELEM_NAMES[dtype]}, lean composition",
          "dtype": dtype, "steps": steps, "warmup": warmup, "value": wl.B * steps / elapsed, "unit": "tokens/s",
-         "ms_per_step": ms, "roofline": roof}
+         "ms_per_step": ms, "repeat": region_stats(regions, steps), "roofline": roof}
+    if cpu_budget_s > 0:
+        import types
+        r["cpu_baseline"] = cpu_baseline(types.SimpleNamespace(B=wl.B, D=wl.D, S=wl.S, lengths_host=wl.lengths_host),
+                                         budget_s=cpu_budget_s)
     del wl
     torch.cuda.empty_cache()
     return r
@@ -711,22 +758,63 @@ def side_config(name, dtype, dev, steps, warmup):
 
 def engine_config(args, dev):
     """The reference's own profiling workload end to end (README.md:54-82: 123 284 tok/s on an unnamed NVIDIA GPU),
-    in a child process so that the engine's allocations and host threads never share this process's timed region."""
+    in a child process so that the engine's allocations and host threads never share this process's timed region.
+    Every configuration is run --engine-repeats times inside its child (a fresh engine each time, same items); `value`
+    is the median run, min / max beside it -- one run is 0.15 s, too short to compare two compositions on."""
     import subprocess
     out = {}
     for label, extra in (("e1_f32_paged_gemm", []), ("e1_f32_paged_gemm_sequential_loop", ["--sequential-loop"]),
                          ("e1_f32_paged_gemm_sequential_loop_reference_launch_sequence",
                           ["--sequential-loop", "--reference-launch-sequence"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "engine", "--gpus", "1", *extra]
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "engine", "--gpus", "1", "--engine-repeats",
+               str(args.engine_repeats), *extra]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             d = json.loads(line)
             out[label] = {"value": d["value"], "unit": d["unit"], "vs_readme_123284": d["vs_baseline"],
-                          "iterations": d["steps"], "seconds": d["config"]["seconds"], "workload": d["config"]["workload"]}
+                          "iterations": d["steps"], "seconds": d["config"]["seconds"], "repeat": d["config"].get("repeat"),
+                          "workload": d["config"]["workload"]}
         except Exception as e:  # a side measurement never takes the bench line down
             out[label] = {"error": str(e)[:300]}
     return out
+
+
+def collective_report(wl, step, args, world, dist, gather, dev, ms_with_gather):
+    """What the N > 1 line carries so that the record proves the collective ran over N ranks: the backend, the number
+    of ranks an all-reduce of ones saw, what the gathered token buffer holds, the all-gather's own duration, and the
+    step time with the gather left out (same state, same K)."""
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)                                          # over the same communicator as the token gather
+    ranks_seen = int(ones.item())
+    assert ranks_seen == world, f"all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}"
+    gather.wait()
+    latest = gather.latest()
+    assert latest.numel() == world * wl.B
+    n_valid = int((latest >= 0).sum().item())                     # every row of every rank is live: no EMPTY (-1) ids
+    # the all-gather on its own: K blocking gathers of the ranks' [rows] int32 buffers
+    buf, outb = gather.inputs[0], gather.outputs[0]
+    for _ in range(3):
+        dist.all_gather_into_tensor(outb, buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dist.all_gather_into_tensor(outb, buf)
+    torch.cuda.synchronize()
+    t_gather = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev)
+    dist.all_reduce(t_gather, op=dist.ReduceOp.MAX)
+    # the same K steps without the gather
+    regions = timed_steps(wl, step, args.steps, args.warmup, world, dist, None, repeats=max(1, args.repeats))
+    t = torch.tensor(regions, device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""),
+            "ranks_seen": ranks_seen, "gathered_token_ids": latest.numel(), "gathered_token_ids_valid": n_valid,
+            "bytes_per_rank_per_step": wl.B * 4, "gather_us_per_step": t_gather.item() * 1e6,
+            "ms_per_step_without_gather": median_region(t.tolist()) / args.steps * 1e3,
+            "ms_per_step_with_gather": ms_with_gather,
+            "note": "the gather is asynchronous (RCCL's stream, beside the next step's kernels), so its blocking "
+                    "duration is not added to the step"}
 
 
 def run_step_bench(args, rank, world, dev, dist):
@@ -739,17 +827,21 @@ def run_step_bench(args, rank, world, dev, dist):
     step = wl.lean_step if lean else wl.step
     step()                                  # per-stream workspaces are allocated outside the timed region
     wl.lengths.copy_(wl.lengths0)
-    elapsed = timed_steps(wl, step, args.steps, args.warmup, world, dist, gather)
+    regions = timed_steps(wl, step, args.steps, args.warmup, world, dist, gather, repeats=max(1, args.repeats))
+    tmax = torch.tensor(regions, device=dev, dtype=torch.float64)
     tokens = torch.tensor([float(wl.B * args.steps)], device=dev)
-    tmax = torch.tensor([elapsed], device=dev)
     if world > 1:
         dist.all_reduce(tokens, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)           # per region: the slowest rank
+    regions = tmax.tolist()
+    elapsed = median_region(regions)
     total_tokens = float(tokens.item())
     form = ("lean composition: what the layers run -- no scores / probabilities / emb_score materialised, chunks merged "
             "inside the scan launch" if lean else
             "materialising composition: the reference's launch sequence, qkt_output probabilities and emb_score written")
+    name = args.workload
+    if args.workload == "c4" and world == 8:
+        name = "c5: 8192 rows over 8 GPUs = c4"          # BASELINE.json configs[4]
     out = {
         "metric": "decode tokens/sec (whole node) on synthetic batch",
         "value": total_tokens / elapsed,
@@ -761,29 +853,36 @@ def run_step_bench(args, rank, world, dev, dist):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": args.dtype,
+        "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8"}[args.dtype],
         "data": "synthetic",
+        "repeat": dict(region_stats(regions, args.steps),
+                       note="every region = exactly `steps` steps from the same state, barrier + synchronize on both sides, "
+                            "max over ranks; `value` / `ms_per_step` are the median region"),
         "config": {
-            "workload": f"{args.workload}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
+            "workload": f"{name}: {wl.layout} KV decode step (attention + greedy decoder head, n_new=0), "
                         f"{wl.B} rows/GPU, emb_dim {wl.D}, max_seq {wl.S}, lengths U[{wl.S // 4},{int(wl.lengths_host.max())}], "
-                        f"{'bf16 pages and weights, fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}; {form}",
-            "rows_per_gpu": wl.B, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
+                        f"{ELEM_NAMES[args.dtype]}{'' if args.dtype == 'f32' else ', fp32 accumulate'}; {form}",
+            "rows_per_gpu": wl.B, "rows_total": wl.B * world, "emb_dim": wl.D, "max_seq": wl.S, "n_vocab": N_VOCAB,
             "mean_length": float(wl.lengths_host.mean()),
             "parallelism": f"row-sharded replicas x{world}, all-gather of token ids",
         },
     }
+    if world > 1:
+        coll = collective_report(wl, step, args, world, dist, gather, dev, out["ms_per_step"])
+        if rank == 0:
+            out["collective"] = coll
     if rank == 0 and not args.no_roofline:
         lengths_now = wl.lengths.cpu().numpy()
         reps = max(10, args.steps)
         roof, times = roofline_report(wl, args.workload, args.dtype, lengths_now, out["ms_per_step"], reps, lean=lean)
         roof["projection_gemm"] = gemm_report(wl, lengths_now, times)
         out["roofline"] = roof
-        if world == 1 and wl.layout == "paged":
+        if world == 1 and wl.layout == "paged" and args.dtype != "fp8":
             # the other form of the same step, same state, same run: K steps each, plus its scan / combine launches
             other = wl.step if lean else wl.lean_step
             other()
             wl.lengths.copy_(wl.lengths0)
-            t_other = timed_steps(wl, other, args.steps, args.warmup, 1, None)
+            t_other = median_region(timed_steps(wl, other, args.steps, args.warmup, 1, None, repeats=max(1, args.repeats)))
             o_roof, _ = roofline_report(wl, args.workload, args.dtype, wl.lengths.cpu().numpy(),
                                         t_other / args.steps * 1e3, reps, lean=not lean)
             mine = {"ms_per_step": out["ms_per_step"], "value": out["value"], "scan_frac": roof["frac"],
@@ -798,24 +897,37 @@ def run_step_bench(args, rank, world, dev, dist):
                                     "is the form config.workload names"}
         if world == 1:
             roof["projection_gemm_d2048"] = large_gemm_report(dev)
-            roof["measured_copy_gbs"] = measure_copy_gbs(dev)
+            roof["measured_read_gbs"] = measure_read_gbs(dev)
+            roof["measured_read_note"] = ("a pure streaming read of 4 GiB (16-byte lane loads, non-temporal, 16 KiB per wave in "
+                                          "flight) on this box: what the scan could reach with no arithmetic and no page table")
     import types
     meta = types.SimpleNamespace(B=wl.B, D=wl.D, S=wl.S, lengths_host=wl.lengths_host)  # all cpu_baseline needs
     del wl
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
-        for name, dtype in (("c2", "f32"), ("c3", "f32"), ("c4", "f32" if args.dtype == "bf16" else "bf16")):
+        others = [("c2", "f32"), ("c3", "f32"), ("c4", "f32"), ("c4", "bf16"), ("c4", "fp8")]
+        for name, dtype in others:
             if name == args.workload and dtype == args.dtype:
                 continue
+            if dtype == "fp8" and not ops.has_fp8():
+                continue
             try:
-                cfgs[f"{name}_{dtype}"] = side_config(name, dtype, dev, args.config_steps, 10)
+                cfgs[f"{name}_{dtype}"] = side_config(name, dtype, dev, args.config_steps, 10, max(1, args.repeats),
+                                                      cpu_budget_s=0.0 if args.no_cpu_baseline or name == "c4" else 4.0)
             except Exception as e:
                 cfgs[f"{name}_{dtype}"] = {"error": str(e)[:300]}
         cfgs["engine"] = engine_config(args, dev)
         out["configs"] = cfgs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(meta)
+    if rank == 0:
+        try:   # nothing this process started may outlive it (engine children, thread pools)
+            import psutil
+            kids = psutil.Process().children(recursive=True)
+            out["children_alive_at_exit"] = [" ".join(k.cmdline())[:80] for k in kids if k.is_running() and k.status() != psutil.STATUS_ZOMBIE]
+        except Exception:
+            pass
     return out
 
 

@@ -401,8 +401,12 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  *                      rounding order of the fp32 accumulation) */
 int mli_tune(const char* key, int value);
 
-/* float4 device copy used by bench.py to measure the achievable HBM copy rate on the box. */
+/* float4 device copy (kept for tools; a copy is not a ceiling for a read stream). */
 int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream);
+/* Pure streaming read of n_floats (a multiple of 16384) with the scan's load shape -- 16-byte non-temporal lane loads,
+ * 16 KiB per wave in flight, nothing written: the box's read-only HBM rate, which bench.py reports beside the scan's
+ * (`roofline.measured_read_gbs`).  sink: >= 1 float of device memory, never written in practice. */
+int mli_stream_read(const float* src, float* sink, size_t n_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mli_clone_inp_embedding_k_v_cache": [_P] * 5 + [_I] * 3 + [_P],
     "mli_tune": [ctypes.c_char_p, _I],
     "mli_stream_copy": [_P, _P, _Z, _P],
+    "mli_stream_read": [_P, _P, _Z, _P],
 }
 class EngineConfig(ctypes.Structure):
     """mli_engine_config (include/mli_engine.h)."""

@@ -455,6 +455,28 @@ __global__ __launch_bounds__(kScanThreads) void stream_copy_kernel(const float4*
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// Pure streaming read: every wave streams its own contiguous region, 16 x 1 KiB non-temporal 16-byte lane loads in
+// flight, nothing written (the sums go nowhere unless they hit a value they never hit).  The read-only ceiling bench.py
+// holds the scan against.
+__global__ __launch_bounds__(kScanThreads) void stream_read_kernel(const float4* __restrict__ src, float* __restrict__ sink,
+                                                                   size_t n4, size_t f4_per_wave) {
+    constexpr int UNROLL = 16;
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t wave = ((size_t)blockIdx.x * kScanThreads + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * kScanThreads) >> 6;
+    float acc = 0.f;
+    for (size_t base = wave * f4_per_wave; base + f4_per_wave <= n4; base += nwaves * f4_per_wave) {
+        for (size_t o = 0; o < f4_per_wave; o += (size_t)kWave * UNROLL) {
+            float4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = ldg4<true>(reinterpret_cast<const float*>(src + base + o + u * kWave + lane));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
@@ -753,6 +775,14 @@ int mli_stream_copy(const float* src, float* dst, size_t n_floats, void* stream)
     if (n_floats % 4 != 0) return MLI_ERR_BAD_ARG;
     hipLaunchKernelGGL(mli::stream_copy_kernel, dim3(256 * 16), dim3(mli::kScanThreads), 0, mli::as_stream(stream),
                        reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n_floats / 4);
+    return mli::launch_status();
+}
+
+int mli_stream_read(const float* src, float* sink, size_t n_floats, void* stream) {
+    const size_t f4_per_wave = 4096;   // 64 KiB per wave and pass
+    if (n_floats % (4 * f4_per_wave) != 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mli::stream_read_kernel, dim3(256 * 8), dim3(mli::kScanThreads), 0, mli::as_stream(stream),
+                       reinterpret_cast<const float4*>(src), sink, n_floats / 4, f4_per_wave);
     return mli::launch_status();
 }
 

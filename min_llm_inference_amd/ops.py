@@ -414,3 +414,7 @@ def launch_clone_inp_embedding_k_v_cache(page_table, inp_embedding, kt_cache, v_
 
 def stream_copy(src, dst):
     _check(load_library().mli_stream_copy(_p(src), _p(dst), src.numel(), _stream()), "mli_stream_copy")
+
+
+def stream_read(src, sink):
+    _check(load_library().mli_stream_read(_p(src), _p(sink), src.numel(), _stream()), "mli_stream_read")

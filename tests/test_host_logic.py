@@ -26,4 +26,4 @@ def test_pipelined_loop_logic_against_sequential_loop_cpu():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     r = subprocess.run([os.path.join(cpp, "build", "pipelined_logic_test")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failure(s)" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("[ OK ]") == 77
+    assert r.stdout.count("[ OK ]") == 141   # 70 random + 60 tight pools + 4 page-boundary EOF + 7 too-small pools
