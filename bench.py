@@ -61,9 +61,11 @@ class Workload:
         self.name = name
         self.layout, self.B, self.D, self.S = WORKLOADS[name]
         self.dtype = dtype
-        self.esize = 2 if dtype == "bf16" else 4  # bytes per KV / weight element
-        if dtype == "bf16" and self.layout != "paged":
-            raise SystemExit("bf16 is implemented for the paged layout (BASELINE config 4)")
+        self.esize = {"f32": 4, "bf16": 2, "fp8": 1}[dtype]  # bytes per page element (K, V, x)
+        self.wsize = 4 if dtype == "f32" else 2              # bytes per weight element (fp8 pages: bf16 weights)
+        self.elem = {"f32": ops.ELEM_F32, "bf16": ops.ELEM_BF16, "fp8": ops.ELEM_FP8}[dtype]
+        if dtype != "f32" and self.layout != "paged":
+            raise SystemExit("bf16 / fp8 are implemented for the paged layout (BASELINE config 4)")
         B, D, S = self.B, self.D, self.S
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
@@ -85,7 +87,7 @@ class Workload:
 
         sc = 1.0 / np.sqrt(D)
         self.wk, self.wq, self.wv = (u(D, D, scale=sc) for _ in range(3))
-        if dtype == "bf16":
+        if dtype != "f32":
             self.wk, self.wq, self.wv = (w.to(torch.bfloat16) for w in (self.wk, self.wq, self.wv))
         self.emb_table = u(N_VOCAB, D)
         self.emb_table[ops.EOF_TOKEN_ID] = 0  # EOF never wins the argmax: the batch stays full while timing
@@ -102,11 +104,14 @@ class Workload:
             total = sum(per_row)
             block = PAGE * 3 * D
             self.pool = torch.empty(total * block, device=dev,
-                                    dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+                                    dtype={"f32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.uint8}[dtype])
             chunk = 1 << 28
             for o in range(0, self.pool.numel(), chunk):  # K/V/x contents: U(-1,1)
                 n = min(chunk, self.pool.numel() - o)
-                self.pool[o:o + n] = u(n).to(self.pool.dtype)
+                if dtype == "fp8":   # OCP e4m3 codes, by the conversion the page kernels use
+                    ops.f32_to_fp8(u(n), self.pool[o:o + n])
+                else:
+                    self.pool[o:o + n] = u(n).to(self.pool.dtype)
             order = rng.permutation(total)
             if os.environ.get("MLI_BENCH_POOL_ORDER") == "linear":  # diagnostic: pages handed out in address order
                 order = np.arange(total)
@@ -128,6 +133,8 @@ class Workload:
         torch.cuda.synchronize()
 
     def attention(self):
+        if self.dtype == "fp8":
+            raise SystemExit("fp8 pages have the lean composition only")
         if self.dtype == "bf16":
             ops.paged_attention_bf16(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx,
                                      self.q_output, self.qkt_output, self.attention_result, 0, self.S)
@@ -173,14 +180,14 @@ class Workload:
     def lean_attention(self):
         if self.layout == "paged":
             ops.paged_attention_lean(self.page_table, self.lengths, self.wk, self.wq, self.wv, self.new_idx,
-                                     self.q_output, self.attention_result, 0, self.S)
+                                     self.q_output, self.attention_result, 0, self.S, elem=self.elem)
         else:  # the contiguous layout keeps K transposed: its two passes need the score buffer between them
             self.attention()
 
     def fused_decoder(self):
         if self.layout == "paged":
             ops.paged_decoder_fused(self.attention_result, self.emb_table, self.wpe, self.page_table, self.lengths,
-                                    self.decoder_result, 0, self.dtype == "bf16")
+                                    self.decoder_result, 0, self.elem)
         else:
             ops.decoder_fused(self.attention_result, self.emb_table, self.wpe, self.inp_embedding, self.lengths,
                               self.decoder_result.view(-1))
@@ -202,7 +209,7 @@ class Workload:
                 args = (p(self.page_table), p(self.lengths), p(self.wk), p(self.wq), p(self.wv),
                                    p(self.emb_table), p(self.wpe), p(self.q_output), p(self.attention_result),
                                    p(self.decoder_result), self.B, self.S, self.D, N_VOCAB, 1, 0,
-                                   int(self.dtype == "bf16"), p(ws), need, p(sc), sc_need, ctypes.c_void_p(stream))
+                                   self.elem, p(ws), need, p(sc), sc_need, ctypes.c_void_p(stream))
             else:
                 fn = lib.mli_decode_step
                 args = (p(self.inp_embedding), p(self.lengths), p(self.wk), p(self.wq), p(self.wv),
@@ -219,11 +226,10 @@ class Workload:
     def kernels(self, lean=True):
         """name -> callable for every launch of one decode step, in order.  lean = what the layers run."""
         w = self
-        bf = self.dtype == "bf16"
+        bf = self.elem
         if self.layout == "paged":
-            latest = (ops.launch_get_latest_k_q_v_paged_attention_bf16 if bf else ops.launch_get_latest_k_q_v_paged_attention)
-            k = {"get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: latest(
-                w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S)}
+            k = {"get_latest_k_q_v_paged (MFMA gather-GEMM-scatter)": lambda: ops.get_latest_k_q_v_paged_lean(
+                w.page_table, w.lengths, w.wk, w.wq, w.wv, w.q_output, w.S, elem=w.elem)}
             if lean:
                 k[SCAN_LEAN] = lambda: ops.decode_scan_paged(w.q_output, w.page_table, w.lengths, None, w.attention_result,
                                                              bf, phases=7, n_sequence=w.S)
@@ -255,14 +261,14 @@ class Workload:
     def algorithmic_bytes(self, lengths):
         """Per-launch algorithmic HBM bytes (DESIGN.md 'Roofline accounting'); e = bytes per KV/weight element."""
         L = lengths.astype(np.int64)
-        B, D, e = self.B, self.D, self.esize
+        B, D, e, we = self.B, self.D, self.esize, self.wsize
         live = int((L > 0).sum())
         ptrs = int((8 * -(-L // PAGE)).sum()) if self.layout == "paged" else 0
         kv_one = int(L.sum()) * D * e
         qkt = kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4       # K + q in, scores out
         sv = kv_one + int(L.sum()) * 4 + live * D * 4 + ptrs + B * 4        # V + probs in, result out
-        latest = live * D * (3 * e + 4) + 3 * D * D * e + B * 4 + (8 * live if self.layout == "paged" else 0)
-        step = (2 * kv_one + live * (3 * D * e + D * 4) + 3 * D * D * e + B * 4 + ptrs)  # SURVEY 8(d)
+        latest = live * D * (3 * e + 4) + 3 * D * D * we + B * 4 + (8 * live if self.layout == "paged" else 0)
+        step = (2 * kv_one + live * (3 * D * e + D * 4) + 3 * D * D * we + B * 4 + ptrs)  # SURVEY 8(d)
         scan = 2 * kv_one + live * D * 4 + int(L.sum()) * 4 + ptrs + B * 4   # K + V + q in, raw scores out
         scan_lean = 2 * kv_one + 2 * live * D * 4 + ptrs + B * 4             # K + V + q in, attention_result out
         return {"qkt": qkt, "softmax_v": sv, "scan": scan, "scan_lean": scan_lean, "get_latest": latest, "step": step}
@@ -364,7 +370,7 @@ def cpu_baseline(wl, budget_s=12.0):
                           "sample": f"{mt_reps} steps over the same rows split across {nthr} threads, {mt_t:.1f} s"}}
 
 
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 2500.0}  # (fp8 pages: the projection multiplies in bf16)  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def gemm_report(wl, lengths, times):
@@ -439,7 +445,8 @@ def run_engine_mode(args, rank, world, dev):
 
     emb = u(V, D)
     emb[ops.EOF_TOKEN_ID] *= 1.0001  # the reference scales the EOF row the same way
-    kind = {"paged": eng.PAGED, "paged_gemm": eng.PAGED_GEMM, "paged_bf16": eng.PAGED_BF16}[args.engine_kind]
+    kind = {"paged": eng.PAGED, "paged_gemm": eng.PAGED_GEMM, "paged_bf16": eng.PAGED_BF16,
+            "paged_fp8": eng.PAGED_FP8}[args.engine_kind]
     # page pool: the reference gives 4 pages per slot at S = 128, i.e. half of the worst case B * S / 16 -- rows
     # outgrow it, so page growth and preemption are part of the measured run (mode E)
     n_blocks = B * S // 32
@@ -525,9 +532,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
-    ap.add_argument("--dtype", choices=["auto", "f32", "bf16"], default="auto",
+    ap.add_argument("--dtype", choices=["auto", "f32", "bf16", "fp8"], default="auto",
                     help="KV page / weight element type (accumulation, q, scores and outputs are always fp32); "
-                         "auto = what BASELINE.json names for the workload: bf16 for c4, fp32 for c2/c3")
+                         "auto = what BASELINE.json names for the workload: bf16 for c4, fp32 for c2/c3; fp8 = the opt-in "
+                         "extension (OCP e4m3 pages, bf16 weights; lean composition only) -- never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
@@ -538,8 +546,9 @@ def main():
                          "headline instead of the lean composition the layers run")
     ap.add_argument("--mode", choices=["step", "engine"], default="step",
                     help="step: kernel-level decode step (default); engine: the reference's profiling workload end to end")
-    ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16"], default="paged_gemm",
-                    help="paged_bf16 = extension: bf16 pages and weights (BASELINE config 4 dtype)")
+    ap.add_argument("--engine-kind", choices=["paged", "paged_gemm", "paged_bf16", "paged_fp8"], default="paged_gemm",
+                    help="paged_bf16 = extension: bf16 pages and weights (BASELINE config 4 dtype); paged_fp8 = opt-in "
+                         "extension: fp8 (OCP e4m3) pages, bf16 weights")
     ap.add_argument("--pipelined", action="store_true",
                     help="engine mode: insist on the pipelined loop (host one step behind the GPU; per-slot device "
                          "updates) -- it is the default wherever it applies")
@@ -623,8 +632,8 @@ def main():
                 "unit": "tokens/s", "n_gpus": world, "steps": int(st.iterations), "warmup": 0,
                 "ms_per_step": sec.item() / max(int(st.iterations), 1) * 1e3, "higher_is_better": True,
                 "scaling": "weak",
-                "vs_baseline": tok.item() / sec.item() / world / 123284.0 if ref_shape and args.engine_kind != "paged_bf16" else None,
-                "dtype": "bf16" if args.engine_kind == "paged_bf16" else "f32",
+                "vs_baseline": tok.item() / sec.item() / world / 123284.0 if ref_shape and args.engine_kind in ("paged", "paged_gemm") else None,
+                "dtype": {"paged_bf16": "bf16", "paged_fp8": "fp8"}.get(args.engine_kind, "f32"),
                 "data": "synthetic",
                 "config": {"workload": ("engine: reference tests/paged_for_profile.cpp workload" if ref_shape else
                                         f"engine: {args.workload} shape under the reference's profiling recipe") +

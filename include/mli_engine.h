@@ -20,7 +20,11 @@ typedef struct mli_engine mli_engine;
 /* MLI_ENGINE_PAGED_BF16 is an EXTENSION (the reference is fp32 only): the paged GEMM engine over bf16 pages and
  * bf16 Wk/Wq/Wv (the fp32 host weights are rounded to nearest-even at creation); emb_dim % 8 == 0; a page is
  * 16 * 3 * emb_dim bf16 elements. */
-enum { MLI_ENGINE_CONTIGUOUS = 0, MLI_ENGINE_PAGED = 1, MLI_ENGINE_PAGED_GEMM = 2, MLI_ENGINE_PAGED_BF16 = 3 };
+/* MLI_ENGINE_PAGED_FP8 is an EXTENSION, opt-in: OCP e4m3 pages (x, K and V: one byte per element under
+ * the same layout rule, a page is 16 * 3 * emb_dim bytes), bf16 Wk/Wq/Wv, fp32 everywhere else; emb_dim % 16 == 0; lean
+ * compositions only. */
+enum { MLI_ENGINE_CONTIGUOUS = 0, MLI_ENGINE_PAGED = 1, MLI_ENGINE_PAGED_GEMM = 2, MLI_ENGINE_PAGED_BF16 = 3,
+       MLI_ENGINE_PAGED_FP8 = 4 };
 
 typedef struct {
     int kind;             /* MLI_ENGINE_* */

@@ -42,6 +42,17 @@ extern "C" {
 /* ABI version; bumped whenever a signature below changes. */
 int mli_abi_version(void);
 
+/* Page / weight element types of the lean entry points (their `elem` argument; the reference is fp32 only):
+ *   MLI_ELEM_F32   float pages and weights -- the reference's types
+ *   MLI_ELEM_BF16  EXTENSION: bfloat16 pages and weights (BASELINE config 4)
+ *   MLI_ELEM_FP8   EXTENSION, opt-in: OCP e4m3 pages (x, K and V segments; one byte per element under the same layout
+ *                  rule), bfloat16 weights; q, scores, softmax and every accumulation stay fp32
+ * mli_elem_supported: 1 when this build implements the element type, 0 otherwise. */
+#define MLI_ELEM_F32 0
+#define MLI_ELEM_BF16 1
+#define MLI_ELEM_FP8 2
+int mli_elem_supported(int elem);
+
 /* Bytes of device scratch the split-sequence kernels need for a problem of this size
  * (softmax_v / softmax_v_paged / paged_attention / inference_self_attention): per-chunk softmax statistics,
  * the split-sequence partial sums, and -- in a fixed 64 KiB region at the front, so that calls of different shapes can
@@ -189,6 +200,13 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths,
                              float* q_output, float* attention_result,
                              int n_batch, int n_sequence, int emb_dim, int n_new_items, int elem_bf16,
                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* The decode projection of mli_paged_attention_lean on its own (q, k, v of every non-empty row's last token; k, v appended to
+ * the page, q to q_output) for any page element type: elem = MLI_ELEM_*.  For fp32 / bf16 pages it is
+ * mli_get_latest_k_q_v_paged[_bf16]; fp8 pages have no other entry point for it.  (bench.py times it apart from the scan.) */
+int mli_get_latest_k_q_v_paged_lean(void* const* page_table, const int* lengths, const void* wk, const void* wq,
+                                    const void* wv, float* q_output, int n_batch, int n_sequence, int emb_dim, int elem,
+                                    void* stream);
 
 /* LEAN contiguous composition -- what SelfAttentionLayer::forward runs: inference_self_attention
  * (self_attention_inference_optimized.h:22-25) without its qkt_output scratch (nothing downstream reads it,
@@ -340,6 +358,10 @@ int mli_graph_destroy(void* graph_exec);
 int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp_embedding,
                                       const float* kt_cache, const float* v_cache, const int* lengths,
                                       int n_batch, int n_sequence, int emb_dim, void* stream);
+
+/* fp32 -> fp8 (OCP e4m3fn; round to nearest even, saturating at +-448, NaN kept) with the conversion the fp8 page kernels
+ * use: n (a multiple of 4) values.  For building synthetic fp8 pages in tests and bench.py. */
+int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream);
 
 /* Tuning / diagnostic knobs (process-wide; results are identical for every setting):
  *   "chunk_tokens"     0 = heuristic, else a power of two in [64, 1024]: tokens per workgroup of the

@@ -41,6 +41,7 @@ _Z = ctypes.c_size_t
 # name -> argtypes; restype is int unless listed in _RESTYPES.  Mirrors include/mli_kernels.h 1:1.
 SIGNATURES = {
     "mli_abi_version": [],
+    "mli_elem_supported": [_I],
     "mli_attention_workspace_bytes": [_I, _I, _I],
     "mli_attention_workspace_init": [_P, _Z, _P],
     "mli_fill_new_kt_v_cache": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mli_paged_decoder_multi_rounds_bf16": [_P] * 7 + [_I] * 6 + [_P],
     "mli_decode_scan_paged": [_P] * 5 + [_I] * 5 + [_P, _Z, _P],
     "mli_paged_attention_lean": [_P] * 8 + [_I] * 5 + [_P, _Z, _P],
+    "mli_get_latest_k_q_v_paged_lean": [_P] * 6 + [_I] * 4 + [_P],
     "mli_self_attention_lean": [_P] * 10 + [_I] * 5 + [_P, _Z, _P],
     "mli_decode_scan_contiguous": [_P] * 5 + [_I] * 3 + [_P, _Z, _P],
     "mli_decoder_scratch_bytes": [_I, _I],
@@ -86,6 +88,7 @@ SIGNATURES = {
     "mli_tune": [ctypes.c_char_p, _I],
     "mli_stream_copy": [_P, _P, _Z, _P],
     "mli_stream_read": [_P, _P, _Z, _P],
+    "mli_f32_to_fp8": [_P, _P, _Z, _P],
 }
 class EngineConfig(ctypes.Structure):
     """mli_engine_config (include/mli_engine.h)."""

@@ -92,7 +92,7 @@ __device__ __forceinline__ int longest_first_row(const int* __restrict__ lengths
     return found_row;
 }
 
-template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false, bool SCORES = true>
+template <class E, int NJ, bool NT, int TBR, int MINW, int WAVES, bool DS = false, bool SCORES = true, int RPI = 1>
 __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* ml, float* partial,
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
         b = (int)(item % gridDim.x);
         c = (int)(item / gridDim.x);
     }
-    fused_scan_item<E, NJ, NT, TBR, WAVES, DS, SCORES>(q, page_table, lengths, qkt, out, ml, partial, S, D, ct, ml_per_row,
-                                                        nchunk_max, direct, tail, slots, arrivals, b, c, c == 0,
-                                                        (int)gridDim.x, smem_raw, ScanNoGate{});
+    fused_scan_item<E, NJ, NT, TBR, WAVES, DS, SCORES, ScanNoGate, RPI>(q, page_table, lengths, qkt, out, ml, partial, S, D, ct,
+                                                                         ml_per_row, nchunk_max, direct, tail, slots, arrivals,
+                                                                         b, c, c == 0, (int)gridDim.x, smem_raw, ScanNoGate{});
 }
 
 // grid = (B, kCombineParts).  Every part merges the row's chunk statistics (cheap, identical result), part 0 also
@@ -220,6 +220,10 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
     if (!g_flash || nj > 8 || D % E::EPL != 0 || S % kPage != 0) return 0;
+    constexpr bool kFp8 = std::is_same<E, ElemFP8>::value;
+    if (kFp8 && (!lean || nj > 2)) return 0;   // the fp8 extension: lean form, rows of up to two lane loads (emb_dim <= 2048)
+    // fp8 rows narrower than one load instruction: 2 or 4 token slots per instruction (scan_common.hpp)
+    const int rpi = kFp8 ? (Du <= 16 ? 4 : Du <= 32 ? 2 : 1) : 1;
     const bool dsplit = nj > 2;  // wide rows: the four waves split the row instead of the pages
     const int nj_ds = ceil_div_i(Du, kWave * kFuWaves);  // 1 or 2
     // variant 3: single-wave workgroups of 128 tokens -- every wave is its own scheduling unit, no LDS merge,
@@ -256,7 +260,7 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     }
     const int waves = solo ? 1 : kFuWaves;
     // page pointers of the chunk | reduction buffer (also holds the row's chunk statistics during the in-kernel merge)
-    const size_t red_bytes = (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * kWave * E::EPL) * sizeof(float);
+    const size_t red_bytes = (dsplit ? (size_t)2 * kFuWaves * 16 : (size_t)waves * nj * (kWave / rpi) * E::EPL) * sizeof(float);
     const size_t stat_bytes_row = (size_t)ml_per_row * 8;  // upper bound of the triples a row can have
     const size_t smem = (size_t)(ct / kPage) * 8 + (red_bytes > stat_bytes_row ? red_bytes : stat_bytes_row);
     dim3 grid(B, nchunk);
@@ -277,7 +281,23 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
     hipLaunchKernelGGL((fused_decode_scan_kernel<E, NJ, NT, TBR, MINW, WAVES, ##__VA_ARGS__>), grid,               \
                        dim3(WAVES * kWave), smem, st, q, page_table, lengths, qkt, out, ml, partial, S, D, ct,     \
                        ml_per_row, nchunk, direct, ticket, tail, slots, arrivals)
-    if ((phases & 1) && lean) {
+    if constexpr (kFp8) {
+        if (phases & 1) {
+            if (rpi == 4) {
+                if (nt) MLI_FU_LAUNCH(1, true, 2, 2, 4, false, false, 4);
+                else MLI_FU_LAUNCH(1, false, 2, 2, 4, false, false, 4);
+            } else if (rpi == 2) {
+                if (nt) MLI_FU_LAUNCH(1, true, 4, 2, 4, false, false, 2);
+                else MLI_FU_LAUNCH(1, false, 4, 2, 4, false, false, 2);
+            } else if (nj == 1) {
+                if (nt) MLI_FU_LAUNCH(1, true, 8, 2, 4, false, false);
+                else MLI_FU_LAUNCH(1, false, 8, 2, 4, false, false);
+            } else {
+                if (nt) MLI_FU_LAUNCH(2, true, 4, 2, 4, false, false);
+                else MLI_FU_LAUNCH(2, false, 4, 2, 4, false, false);
+            }
+        }
+    } else if ((phases & 1) && lean) {
         // the default register budget only (the variants are tuning experiments of the materialising form)
         if (dsplit) {
             if (nj_ds == 1) {
@@ -371,6 +391,13 @@ int launch_fused_decode_bf16(const float* q, const uint16_t* const* page_table, 
                                          ws, ws_bytes, st, qkt == nullptr ? 7 : 3);
 }
 
+// fp8 (OCP e4m3) pages: the lean form only
+int launch_fused_decode_fp8(const float* q, const uint8_t* const* page_table, const int* lengths, float* out, int B, int S,
+                            int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    return launch_fused_decode<ElemFP8>(q, reinterpret_cast<const void* const*>(page_table), lengths, nullptr, out, B, S, D, ws,
+                                        ws_bytes, st, 7);
+}
+
 }  // namespace mli
 
 extern "C" int mli_decode_scan_paged(const float* q_output, const void* const* page_table, const int* lengths,
@@ -381,7 +408,12 @@ extern "C" int mli_decode_scan_paged(const float* q_output, const void* const* p
     if (phases < 1 || phases > 7 || phases == 4) return MLI_ERR_BAD_ARG;
     if (!(phases & 4) && qkt_output == nullptr) return MLI_ERR_BAD_ARG;
     hipStream_t st = mli::as_stream(stream);
-    const int r = elem_bf16 ? mli::launch_fused_decode<mli::ElemBF16>(q_output, page_table, lengths, qkt_output,
+    if (elem_bf16 < MLI_ELEM_F32 || elem_bf16 > MLI_ELEM_FP8) return MLI_ERR_BAD_ARG;
+    if (elem_bf16 == MLI_ELEM_FP8 && !(phases & 4)) return MLI_ERR_BAD_ARG;   // the fp8 extension has the lean form only
+    const int r = elem_bf16 == MLI_ELEM_FP8
+                      ? mli::launch_fused_decode<mli::ElemFP8>(q_output, page_table, lengths, qkt_output, attention_result,
+                                                               n_batch, n_sequence, emb_dim, workspace, workspace_bytes, st, phases)
+                  : elem_bf16 ? mli::launch_fused_decode<mli::ElemBF16>(q_output, page_table, lengths, qkt_output,
                                                                       attention_result, n_batch, n_sequence, emb_dim,
                                                                       workspace, workspace_bytes, st, phases)
                             : mli::launch_fused_decode<mli::ElemF32>(q_output, page_table, lengths, qkt_output,

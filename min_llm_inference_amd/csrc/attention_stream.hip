@@ -46,13 +46,17 @@ int nt_loads_for(int B, int S, int D, int esize);             // attention_scan.
 size_t stats_region_bytes_for(int B, int S);
 
 // MAXSEG = segments (rows touched) a workgroup finishes per group: their wave partials wait in LDS for the group's merge
-template <class E, int NJ, bool NT, int TBR, int MAXSEG>
-__global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
+// RPI = token slots per load instruction (scan_common.hpp; 1 for the reference's fp32 and for bf16), TBR = load
+// instructions per batch: a batch covers TBR * RPI slots, a page is 2 * 16 / (TBR * RPI) batches
+template <class E, int NJ, bool NT, int TBR, int MAXSEG, int RPI = 1, int WGS = 2>
+__global__ __launch_bounds__(kStThreads, WGS) void fused_decode_stream_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ out, float2* ml, float* partial, unsigned* arrivals, unsigned* ticket, int B, int S, int D,
     int ml_per_row, int max_pages_wg, int dyn_pct, int gran) {
     constexpr int EPL = E::EPL;
-    constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes to a segment's partial
+    constexpr int LPR = kWave / RPI;         // lanes per token row
+    static_assert(RPI == 1 || NJ == 1, "several rows per instruction only for rows of one lane load");
+    constexpr int kRowF = NJ * LPR * EPL;    // floats one wave contributes to a segment's partial
     extern __shared__ __align__(16) unsigned char st_smem[];
     // LDS: prefix[B + 1] | page pointers of the share | q of the group's rows | wave partials | wave (m, l) | lengths of the group's rows
     int* prefix = reinterpret_cast<int*>(st_smem);
@@ -155,13 +159,15 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
     const int block_bytes = kPage * 3 * D * E::kBytes;
     bool live[NJ];
     unsigned voff[NJ];
+    const int lane_u = lane % LPR, lane_grp = lane / LPR;   // unit inside the row, row inside the load instruction
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int u = lane + j * kWave;
+        const int u = lane_u + j * kWave;
         live[j] = u < Du;
-        voff[j] = live[j] ? (unsigned)u * 16u : 0x40000000u;  // beyond the row: outside the descriptor's range, reads zeros
+        // beyond the row: outside the descriptor's range, reads zeros
+        voff[j] = live[j] ? (unsigned)u * 16u + (unsigned)lane_grp * (unsigned)row_bytes : 0x40000000u;
     }
-    constexpr int NB = 16 / TBR;
+    constexpr int NB = 16 / (TBR * RPI);
     constexpr int NPOS = 2 * NB;
     constexpr int PD = 3;
     fu_u32x4 buf[4][TBR][NJ];
@@ -174,12 +180,12 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
         const char* upg = reinterpret_cast<const char*>(wave_uniform(reinterpret_cast<const float*>(pg)));
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(upg), 0, upg != nullptr ? block_bytes : 0, 0x00020000);
-        const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * (int)row_bytes;
+        const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * RPI * (int)row_bytes;
 #pragma unroll
         for (int t = 0; t < TBR; ++t)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * (int)row_bytes, NT ? 2 : 0);
+                buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * RPI * (int)row_bytes, NT ? 2 : 0);
     };
 
     typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
@@ -225,7 +231,10 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) dst[(j * kWave + lane) * EPL + e] = acc[j][e];
+                for (int e = 0; e < EPL; ++e) {
+                    const float a = rpi_group_sum<RPI>(acc[j][e]);   // the lane groups hold different slots' contributions
+                    if (RPI == 1 || lane < LPR) dst[(j * kWave + lane_u) * EPL + e] = a;
+                }
         };
         const int p_first = pg_lo + wave;
         const char* page = p_first < pg_hi ? page_ptr(p_first) : nullptr;
@@ -250,14 +259,14 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         acc[j][e] = 0.f;
-                        qr[j][e] = live[j] ? q_sh[(size_t)(b - r0) * D + (lane + j * kWave) * EPL + e] : 0.f;
+                        qr[j][e] = live[j] ? q_sh[(size_t)(b - r0) * D + (lane_u + j * kWave) * EPL + e] : 0.f;
                     }
             }
             // live tokens of this page: it is page (lo + pi - prefix[cur]) of row cur
             const int nt = min(kPage, seg_len[cur - r0] - (lo + pi - prefix[cur]) * kPage);
-            float sacc[16];
+            float sacc[16 / RPI];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) sacc[t] = 0.f;
+            for (int t = 0; t < 16 / RPI; ++t) sacc[t] = 0.f;
             float p_lane = 0.f;
             static_for<NPOS>([&](auto POS) {
                 constexpr int pos = decltype(POS)::value;
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
                             for (int e = 0; e < EPL; ++e) sacc[pos * TBR + t] = fmaf(qr[j][e], kf[e], sacc[pos * TBR + t]);
                         }
                     if constexpr (pos == NB - 1) {
-                        const float tot = wave_reduce16(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15
-                        const int slot = (lane >> 2) & 15;
+                        const float tot = rpi_reduce<RPI>(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15 (RPI = 1)
+                        const int slot = rpi_slot_of_lane<RPI>(lane);
                         const bool valid = slot < nt;
                         const float score = tot / scale;
                         const float pm = wave_max(valid ? score : -INFINITY);
@@ -298,12 +307,17 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
                     constexpr int first = (pos - NB) * TBR;
 #pragma unroll
                     for (int t = 0; t < TBR; ++t) {
-                        const float p = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p_lane), 4 * (first + t)));
-                        if (first + t < nt) {  // wave-uniform: never multiply unwritten page memory, even by zero
+                        const float p = rpi_prob<RPI>(p_lane, first + t, lane);
+                        if (RPI * (first + t) < nt) {  // wave-uniform: never multiply unwritten page memory, even by zero
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) {
+                                fu_u32x4 raw = buf[bi][t][j];
+                                if constexpr (RPI > 1) {   // (per lane group: a slot beyond the row reads as zeros)
+                                    const bool ok = RPI * (first + t) + lane_grp < nt;
+                                    raw.x = ok ? raw.x : 0u; raw.y = ok ? raw.y : 0u; raw.z = ok ? raw.z : 0u; raw.w = ok ? raw.w : 0u;
+                                }
                                 float vf[EPL];
-                                E::unpack(buf[bi][t][j], vf);
+                                E::unpack(raw, vf);
 #pragma unroll
                                 for (int e = 0; e < EPL; ++e) acc[j][e] = fmaf(p, vf[e], acc[j][e]);
                             }
@@ -494,6 +508,7 @@ bool stream_decode_applies(int B, int S, int D) {
 }
 template bool stream_decode_applies<ElemF32>(int, int, int);
 template bool stream_decode_applies<ElemBF16>(int, int, int);
+template bool stream_decode_applies<ElemFP8>(int, int, int);
 
 // 1 = ran, 0 = not applicable (the caller takes the chunked kernel), else an error (+1 if positive)
 template <class E>
@@ -519,16 +534,18 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
     // a share is at most ceil(P / G) pages where every workgroup works, and below 2 * kStMinPages otherwise
     const int64_t p_max = (int64_t)B * (S / kPage);
     const int max_pages_wg = (int)std::max<int64_t>(std::max<int64_t>((p_max + G - 1) / G + 1, 2 * kStMinPages + 1), g_stream_granule);
-    const int kRowF = nj * kWave * E::EPL;
+    // fp8 rows narrower than one load instruction: 2 or 4 token slots per instruction (scan_common.hpp)
+    const int rpi = std::is_same<E, ElemFP8>::value ? (Du <= 16 ? 4 : Du <= 32 ? 2 : 1) : 1;
+    const int kRowF = nj * (kWave / rpi) * E::EPL;
     const int maxseg = kRowF <= 512 ? 4 : 2;
     const size_t smem = (((size_t)(B + 1) * sizeof(int) + 15) & ~(size_t)15) + (((size_t)max_pages_wg * 8 + 15) & ~(size_t)15) +
                         (size_t)maxseg * D * sizeof(float) + (size_t)maxseg * kStWaves * kRowF * sizeof(float) +
                         (size_t)maxseg * kStWaves * sizeof(float2) + (size_t)maxseg * sizeof(int) + (8 + 3 * (size_t)maxseg + 1) * sizeof(int);
     if ((size_t)ml_per_row * sizeof(float2) > (size_t)maxseg * D * sizeof(float) || smem > 80 * 1024) return 0;
     const bool nt = nt_loads_for(B, S, D, E::kBytes);
-#define MLI_ST_LAUNCH(NJ, NT, TBR, MAXSEG)                                                                              \
+#define MLI_ST_LAUNCH(NJ, NT, TBR, MAXSEG, ...)                                                                         \
     do {                                                                                                                 \
-        auto kern = fused_decode_stream_kernel<E, NJ, NT, TBR, MAXSEG>;                                                  \
+        auto kern = fused_decode_stream_kernel<E, NJ, NT, TBR, MAXSEG, ##__VA_ARGS__>;                                   \
         if (smem > 64 * 1024) {                                                                                          \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess) return (int)e + 1;                                                                      \
@@ -537,7 +554,21 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
                            arrivals + (kMaxArrivalRows - 1), B, S, D, ml_per_row, max_pages_wg, g_stream_dyn_pct,     \
                            g_stream_granule);                                                                            \
     } while (0)
-    if (nj == 1) {
+    if constexpr (std::is_same<E, ElemFP8>::value) {
+        if (rpi == 4) {
+            if (nt) MLI_ST_LAUNCH(1, true, 2, 4, 4);
+            else MLI_ST_LAUNCH(1, false, 2, 4, 4);
+        } else if (rpi == 2) {
+            if (nt) MLI_ST_LAUNCH(1, true, 4, 4, 2);
+            else MLI_ST_LAUNCH(1, false, 4, 4, 2);
+        } else if (nj == 1) {
+            if (nt) MLI_ST_LAUNCH(1, true, 8, 2);
+            else MLI_ST_LAUNCH(1, false, 8, 2);
+        } else {
+            if (nt) MLI_ST_LAUNCH(2, true, 4, 2);
+            else MLI_ST_LAUNCH(2, false, 4, 2);
+        }
+    } else if (nj == 1) {
         if (nt) MLI_ST_LAUNCH(1, true, 8, 4);
         else MLI_ST_LAUNCH(1, false, 8, 4);
     } else if (kRowF <= 512) {
@@ -554,6 +585,7 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
 
 template int launch_stream_decode<ElemF32>(const float*, const void* const*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
 template int launch_stream_decode<ElemBF16>(const float*, const void* const*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
+template int launch_stream_decode<ElemFP8>(const float*, const void* const*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
 
 }  // namespace mli
 

@@ -45,13 +45,21 @@ int launch_fused_decode_naive(const float*, const float*, const float*, const in
 int launch_decode_step_fused(float* const*, int*, const float*, const float*, const float*, const float*, const float*,
                              float*, float*, int*, int, int, int, int, int, int, void*, size_t, void*, size_t, hipStream_t);
 int launch_qkt_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, hipStream_t);
+// fp8 (OCP e4m3) pages with bf16 weights: MLI_ELEM_FP8 of the lean entry points
+int launch_latest_paged_fp8(uint8_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*, float*, int, int,
+                            int, hipStream_t);
+int launch_fill_paged_fp8_embed(const float*, const float*, const int*, uint8_t* const*, const int*, const int*,
+                                const uint16_t*, const uint16_t*, int, int, int, int, hipStream_t);
+int launch_fused_decode_fp8(const float*, const uint8_t* const*, const int*, float*, int, int, int, void*, size_t, hipStream_t);
 int launch_softmax_v_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, void*, size_t,
                                 hipStream_t);
 }  // namespace mli
 
 extern "C" {
 
-int mli_abi_version(void) { return 3; }
+int mli_abi_version(void) { return 4; }
+
+int mli_elem_supported(int elem) { return elem == MLI_ELEM_F32 || elem == MLI_ELEM_BF16 || elem == MLI_ELEM_FP8; }
 
 int mli_paged_attention_lean(void* const* page_table, const int* lengths, const void* wk, const void* wq, const void* wv,
                              const int* new_batch_idx, float* q_output, float* attention_result, int n_batch,
@@ -60,7 +68,17 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths, const 
     { const mli::WsBody body = mli::ws_body(workspace, workspace_bytes); workspace = body.ptr; workspace_bytes = body.bytes; }
     hipStream_t st = mli::as_stream(stream);
     int rc, fused;
-    if (elem_bf16) {
+    if (elem_bf16 < MLI_ELEM_F32 || elem_bf16 > MLI_ELEM_FP8) return MLI_ERR_BAD_ARG;
+    if (elem_bf16 == MLI_ELEM_FP8) {
+        uint8_t* const* pt = reinterpret_cast<uint8_t* const*>(page_table);
+        const mli_bf16 *k = static_cast<const mli_bf16*>(wk), *q = static_cast<const mli_bf16*>(wq), *v = static_cast<const mli_bf16*>(wv);
+        rc = mli::launch_fill_paged_fp8_embed(nullptr, nullptr, nullptr, pt, new_batch_idx, lengths, k, v, n_batch, n_sequence,
+                                              emb_dim, n_new_items, st);
+        if (!rc) rc = mli::launch_latest_paged_fp8(pt, lengths, k, q, v, q_output, n_batch, n_sequence, emb_dim, st);
+        if (rc) return rc;
+        fused = mli::launch_fused_decode_fp8(q_output, pt, lengths, attention_result, n_batch, n_sequence, emb_dim, workspace,
+                                             workspace_bytes, st);
+    } else if (elem_bf16) {
         mli_bf16* const* pt = reinterpret_cast<mli_bf16* const*>(page_table);
         const mli_bf16 *k = static_cast<const mli_bf16*>(wk), *q = static_cast<const mli_bf16*>(wq), *v = static_cast<const mli_bf16*>(wv);
         rc = mli::launch_fill_paged_bf16(pt, new_batch_idx, lengths, k, v, n_batch, n_sequence, emb_dim, n_new_items, st);
@@ -81,6 +99,25 @@ int mli_paged_attention_lean(void* const* page_table, const int* lengths, const 
     // rows too wide for the single-pass kernel (or no workspace): the caller takes the materialising composition
     if (fused == 0) return MLI_ERR_BAD_ARG;
     return fused < 0 ? fused : fused - 1;
+}
+
+int mli_get_latest_k_q_v_paged_lean(void* const* page_table, const int* lengths, const void* wk, const void* wq,
+                                    const void* wv, float* q_output, int n_batch, int n_sequence, int emb_dim, int elem,
+                                    void* stream) {
+    hipStream_t st = mli::as_stream(stream);
+    if (elem == MLI_ELEM_FP8)
+        return mli::launch_latest_paged_fp8(reinterpret_cast<uint8_t* const*>(page_table), lengths, static_cast<const mli_bf16*>(wk),
+                                            static_cast<const mli_bf16*>(wq), static_cast<const mli_bf16*>(wv), q_output, n_batch,
+                                            n_sequence, emb_dim, st);
+    if (elem == MLI_ELEM_BF16)
+        return mli::launch_latest_paged_bf16(reinterpret_cast<mli_bf16* const*>(page_table), lengths, static_cast<const mli_bf16*>(wk),
+                                             static_cast<const mli_bf16*>(wq), static_cast<const mli_bf16*>(wv), q_output, n_batch,
+                                             n_sequence, emb_dim, st);
+    if (elem == MLI_ELEM_F32)
+        return mli::launch_latest_paged(reinterpret_cast<float* const*>(page_table), lengths, static_cast<const float*>(wk),
+                                        static_cast<const float*>(wq), static_cast<const float*>(wv), q_output, n_batch,
+                                        n_sequence, emb_dim, st);
+    return MLI_ERR_BAD_ARG;
 }
 
 int mli_self_attention_lean(const float* inp_embedding, const int* lengths, const float* wk, const float* wq,
@@ -109,7 +146,7 @@ int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk,
                           int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
                           int n_decoder_results, int i_decoder, int elem_bf16, void* workspace, size_t workspace_bytes,
                           void* decoder_scratch, size_t decoder_scratch_bytes, void* stream) {
-    if (!elem_bf16 && n_decoder_results > 0 && i_decoder >= 0 && i_decoder < n_decoder_results) {
+    if (elem_bf16 == MLI_ELEM_F32 && n_decoder_results > 0 && i_decoder >= 0 && i_decoder < n_decoder_results) {
         // small batches: projection, scan, logits + argmax and the token pick as roles of ONE launch
         const mli::WsBody body = mli::ws_body(workspace, workspace_bytes);
         const int fused = mli::launch_decode_step_fused(
@@ -151,6 +188,11 @@ int mli_paged_prefill(const float* emb_table, const float* wpe, const int* inp, 
                       int n_sequence, int emb_dim, int n_new_items, int elem_bf16, void* stream) {
     if (emb_table == nullptr || wpe == nullptr || inp == nullptr) return MLI_ERR_BAD_ARG;
     hipStream_t st = mli::as_stream(stream);
+    if (elem_bf16 < MLI_ELEM_F32 || elem_bf16 > MLI_ELEM_FP8) return MLI_ERR_BAD_ARG;
+    if (elem_bf16 == MLI_ELEM_FP8)
+        return mli::launch_fill_paged_fp8_embed(emb_table, wpe, inp, reinterpret_cast<uint8_t* const*>(page_table),
+                                                new_item_indices, lengths, static_cast<const mli_bf16*>(wk),
+                                                static_cast<const mli_bf16*>(wv), n_batch, n_sequence, emb_dim, n_new_items, st);
     if (elem_bf16)
         return mli::launch_fill_paged_bf16_embed(emb_table, wpe, inp, reinterpret_cast<mli_bf16* const*>(page_table),
                                                  new_item_indices, lengths, static_cast<const mli_bf16*>(wk),

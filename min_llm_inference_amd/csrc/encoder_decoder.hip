@@ -25,16 +25,26 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return cvt(lo) | (cvt(hi) << 16);
 }
 
-// emb + wpe of 4 consecutive columns -> fp32 row or bf16 row
-template <bool BF16>
+// emb + wpe of 4 consecutive columns -> fp32 row, bf16 row or fp8 (OCP e4m3) row; ELEM = MLI_ELEM_* (false / true = f32 / bf16)
+template <int ELEM>
 __device__ __forceinline__ void store_sum4(float* dst_row, int i4, const float4& a, const float4& c) {
     const float4 r = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
-    if (BF16) reinterpret_cast<uint2*>(dst_row)[i4] = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+    if (ELEM == MLI_ELEM_FP8) reinterpret_cast<uint32_t*>(dst_row)[i4] = f32x4_to_fp8x4(r.x, r.y, r.z, r.w);
+    else if (ELEM == MLI_ELEM_BF16) reinterpret_cast<uint2*>(dst_row)[i4] = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
     else reinterpret_cast<float4*>(dst_row)[i4] = r;
 }
 
+// the row of position s in segment `seg` of a page whose elements are ELEM
+template <int ELEM>
+__device__ __forceinline__ float* page_row_ptr(float* page, int s, int D, int seg) {
+    const int64_t off = page_row_offset(s, D, seg);
+    if (ELEM == MLI_ELEM_FP8) return reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(page) + off);
+    if (ELEM == MLI_ELEM_BF16) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page) + off);
+    return page + off;
+}
+
 // One workgroup per (16-token group, new row); one wave per token, lanes along the embedding.
-template <bool PAGED, bool BF16 = false>
+template <bool PAGED, int BF16 = 0>
 __global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
     const float* __restrict__ emb_table, const float* __restrict__ wpe, const int* __restrict__ inp,
     float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const int* __restrict__ lengths,
@@ -58,16 +68,14 @@ __global__ __launch_bounds__(kEdThreads) void encoder_new_rows_kernel(
         const int tok = inp[(int64_t)b * S + s];
         const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
         const float4* p = reinterpret_cast<const float4*>(wpe + (int64_t)s * D);
-        float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + s) * D
-                     : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page_sh) + page_row_offset(s, D, kSegInp))
-                            : page_sh + page_row_offset(s, D, kSegInp);
+        float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + s) * D : page_row_ptr<BF16>(page_sh, s, D, kSegInp);
         for (int i = lane; i < D4; i += kWave) store_sum4<BF16>(dst, i, e[i], p[i]);
     }
 }
 
 // One workgroup per batch row.  argmax keeps the LOWEST index among equal maxima (the reference's
 // host decoder, tests/test_utils.cpp:607-614; its device kernel breaks ties by thread order).
-template <bool PAGED, bool BF16 = false>
+template <bool PAGED, int BF16 = 0>
 __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     const float* __restrict__ emb_score, int* __restrict__ decoder_result, int* __restrict__ lengths,
     float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const float* __restrict__ wpe_table,
@@ -116,9 +124,7 @@ __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
     if (PAGED && page_sh == nullptr) return;  // no page for the next position (a caller bug): skip rather than fault
     const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
     const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
-    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D
-                 : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page_sh) + page_row_offset(L, D, kSegInp))
-                        : page_sh + page_row_offset(L, D, kSegInp);
+    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D : page_row_ptr<BF16>(page_sh, L, D, kSegInp);
     for (int i = threadIdx.x; i < (D >> 2); i += kEdThreads) store_sum4<BF16>(dst, i, e[i], p[i]);
 }
 
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(kEdThreads) void decoder_argmax_kernel(
 // and writes the next input embedding exactly as decoder_argmax_kernel does (reference decoder.cu:128-205).
 constexpr int kFinalizeRows = kEdThreads / kWave;  // batch rows per workgroup
 
-template <bool PAGED, bool BF16 = false>
+template <bool PAGED, int BF16 = 0>
 __global__ __launch_bounds__(kEdThreads) void decoder_finalize_kernel(
     const RowBest* __restrict__ row_best, int n_tiles, int* __restrict__ decoder_result, int* __restrict__ lengths,
     float* __restrict__ inp_embedding, float* const* __restrict__ page_table, const float* __restrict__ wpe_table,
@@ -167,10 +173,18 @@ __global__ __launch_bounds__(kEdThreads) void decoder_finalize_kernel(
     if (PAGED && page == nullptr) return;      // no page for the next position (a caller bug): skip rather than fault
     const float4* e = reinterpret_cast<const float4*>(emb_table + (int64_t)tok * D);
     const float4* p = reinterpret_cast<const float4*>(wpe_table + (int64_t)L * D);
-    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D
-                 : BF16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(page) + page_row_offset(L, D, kSegInp))
-                        : page + page_row_offset(L, D, kSegInp);
+    float* dst = !PAGED ? inp_embedding + ((int64_t)b * S + L) * D : page_row_ptr<BF16>(page, L, D, kSegInp);
     for (int i = lane; i < (D >> 2); i += kWave) store_sum4<BF16>(dst, i, e[i], p[i]);
+}
+
+// fp32 -> fp8 (OCP e4m3, round to nearest even, saturating) with the page kernels' own conversion: test / bench support
+__global__ __launch_bounds__(kEdThreads) void f32_to_fp8_kernel(const float4* __restrict__ src, uint32_t* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * kEdThreads + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kEdThreads;
+    for (; i < n4; i += stride) {
+        const float4 v = src[i];
+        dst[i] = f32x4_to_fp8x4(v.x, v.y, v.z, v.w);
+    }
 }
 
 // grid = (S/16, B).  Positions 0..min(L, S-1) inclusive are cloned (the decoder writes the next
@@ -229,7 +243,7 @@ int mli_paged_attention_encoder_bf16(const float* emb_table, const float* wpe, c
                                      int n_batch, int n_sequence, int emb_dim, int n_new_items, void* stream) {
     if (n_new_items == 0) return 0;
     if (n_new_items < 0 || emb_dim % 8 != 0 || n_sequence % mli::kPage != 0 || n_batch <= 0) return MLI_ERR_BAD_ARG;
-    hipLaunchKernelGGL((mli::encoder_new_rows_kernel<true, true>), dim3(n_sequence / mli::kPage, n_new_items),
+    hipLaunchKernelGGL((mli::encoder_new_rows_kernel<true, MLI_ELEM_BF16>), dim3(n_sequence / mli::kPage, n_new_items),
                        dim3(mli::kEdThreads), 0, mli::as_stream(stream), emb_table, wpe, inp, (float*)nullptr,
                        reinterpret_cast<float* const*>(page_table), lengths, new_item_indices, n_sequence, emb_dim);
     return mli::launch_status();
@@ -245,7 +259,7 @@ int mli_paged_decoder_multi_rounds_bf16(const float* batch_result, const float* 
     hipStream_t st = mli::as_stream(stream);
     int rc = mli::launch_gemm_nt(batch_result, emb_table, emb_score, n_batch, n_vocab, emb_dim, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((mli::decoder_argmax_kernel<true, true>), dim3(n_batch), dim3(mli::kEdThreads), 0, st,
+    hipLaunchKernelGGL((mli::decoder_argmax_kernel<true, MLI_ELEM_BF16>), dim3(n_batch), dim3(mli::kEdThreads), 0, st,
                        emb_score, decoder_result, lengths, (float*)nullptr,
                        reinterpret_cast<float* const*>(page_table), wpe_table, emb_table, n_vocab, n_sequence,
                        emb_dim, n_decoder_results, i_decoder);
@@ -286,12 +300,12 @@ size_t mli_decoder_scratch_bytes(int n_batch, int n_vocab) {
     return (size_t)n_batch * mli::gemm_nt_argmax_max_tiles(n_vocab) * sizeof(mli::RowBest);
 }
 
-// layout: 0 = contiguous (inp_embedding), 1 = paged fp32, 2 = paged bf16
+// layout: 0 = contiguous (inp_embedding), 1 = paged fp32, 2 = paged bf16, 3 = paged fp8
 static int decoder_fused(int layout, const float* batch_result, const float* emb_table, const float* wpe_table,
                          float* inp_embedding, float* const* page_table, int* lengths, int* decoder_result, int n_batch,
                          int n_vocab, int n_sequence, int emb_dim, int n_decoder_results, int i_decoder, void* scratch,
                          size_t scratch_bytes, void* stream) {
-    if (emb_dim % (layout == 2 ? 8 : 4) != 0 || n_batch <= 0 || n_vocab <= 0 || n_decoder_results <= 0 || i_decoder < 0 ||
+    if (emb_dim % (layout == 3 ? 16 : layout == 2 ? 8 : 4) != 0 || n_batch <= 0 || n_vocab <= 0 || n_decoder_results <= 0 || i_decoder < 0 ||
         i_decoder >= n_decoder_results || (layout != 0 && n_sequence % mli::kPage != 0))
         return MLI_ERR_BAD_ARG;
     if (scratch == nullptr || scratch_bytes < mli_decoder_scratch_bytes(n_batch, n_vocab)) return MLI_ERR_WORKSPACE;
@@ -309,8 +323,12 @@ static int decoder_fused(int layout, const float* batch_result, const float* emb
         hipLaunchKernelGGL((mli::decoder_finalize_kernel<true>), grid, block, 0, st, best, n_tiles, decoder_result, lengths,
                            (float*)nullptr, page_table, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
                            n_decoder_results, i_decoder);
+    else if (layout == 2)
+        hipLaunchKernelGGL((mli::decoder_finalize_kernel<true, MLI_ELEM_BF16>), grid, block, 0, st, best, n_tiles, decoder_result,
+                           lengths, (float*)nullptr, page_table, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
+                           n_decoder_results, i_decoder);
     else
-        hipLaunchKernelGGL((mli::decoder_finalize_kernel<true, true>), grid, block, 0, st, best, n_tiles, decoder_result,
+        hipLaunchKernelGGL((mli::decoder_finalize_kernel<true, MLI_ELEM_FP8>), grid, block, 0, st, best, n_tiles, decoder_result,
                            lengths, (float*)nullptr, page_table, wpe_table, emb_table, n_batch, n_sequence, emb_dim,
                            n_decoder_results, i_decoder);
     return mli::launch_status();
@@ -327,9 +345,17 @@ int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, c
                             void* const* page_table, int* lengths, int* decoder_result, int n_batch, int n_vocab,
                             int n_sequence, int emb_dim, int n_decoder_results, int i_decoder, int elem_bf16, void* scratch,
                             size_t scratch_bytes, void* stream) {
-    return decoder_fused(elem_bf16 ? 2 : 1, batch_result, emb_table, wpe_table, nullptr,
+    if (elem_bf16 < MLI_ELEM_F32 || elem_bf16 > MLI_ELEM_FP8) return MLI_ERR_BAD_ARG;
+    return decoder_fused(1 + elem_bf16, batch_result, emb_table, wpe_table, nullptr,
                          reinterpret_cast<float* const*>(page_table), lengths, decoder_result, n_batch, n_vocab,
                          n_sequence, emb_dim, n_decoder_results, i_decoder, scratch, scratch_bytes, stream);
+}
+
+int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream) {
+    if (n % 4 != 0) return MLI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mli::f32_to_fp8_kernel, dim3(1024), dim3(mli::kEdThreads), 0, mli::as_stream(stream),
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<uint32_t*>(dst), n / 4);
+    return mli::launch_status();
 }
 
 int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp_embedding, const float* kt_cache,

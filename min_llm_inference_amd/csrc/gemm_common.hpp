@@ -160,7 +160,27 @@ __device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive 
                        __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
 }
 
-template <int MODE, bool BF16>
+// fp8 (OCP e4m3fn) <-> fp32 for the fp8 page extension.  Decoding is exact (e4m3 is a subset of bf16 and fp32); encoding
+// rounds to nearest even and SATURATES at +-448 (the format has no infinity), NaN stays NaN (0x7f).
+__device__ __forceinline__ uint32_t f32_to_fp8(float f) {
+    if (f != f) return 0x7fu;
+    const float c = __builtin_amdgcn_fmed3f(f, -448.f, 448.f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, c, 0, false) & 0xffu;
+}
+__device__ __forceinline__ uint32_t f32x4_to_fp8x4(float a, float b, float c, float d) {   // 4 consecutive elements
+    return f32_to_fp8(a) | (f32_to_fp8(b) << 8) | (f32_to_fp8(c) << 16) | (f32_to_fp8(d) << 24);
+}
+// 4 fp8 (one dword) -> 4 bf16 (two dwords): decode to fp32, keep the upper halves (exact)
+__device__ __forceinline__ uint2 fp8x4_to_bf16x4(uint32_t w) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+    return make_uint2((__float_as_uint(lo.x) >> 16) | (__float_as_uint(lo.y) & 0xffff0000u),
+                      (__float_as_uint(hi.x) >> 16) | (__float_as_uint(hi.y) & 0xffff0000u));
+}
+
+// BF16: 16-bit page elements; FP8 (with BF16 set: bf16 weights): 8-bit page elements -- same layout rule either way
+template <int MODE, bool BF16, bool FP8 = false>
 __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, int out_id) {
     RowDesc r{nullptr, nullptr, nullptr, nullptr};
     if (MODE == kPlain) {
@@ -199,7 +219,12 @@ __device__ __forceinline__ RowDesc resolve_row(const GemmArgs& g, int m, int z, 
     } else {
         float* page = g.page_table[(int64_t)b * (g.S / kPage) + s / kPage];
         if (page == nullptr) return r;  // row longer than its pages (a caller bug): skipped, not dereferenced
-        if (BF16) {  // same layout rule, 16-bit elements
+        if (FP8) {  // same layout rule, 8-bit elements
+            uint8_t* tok = reinterpret_cast<uint8_t*>(page) + page_row_offset(s, g.K, kSegInp);
+            r.a = reinterpret_cast<const float*>(tok);
+            if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;  // q stays fp32
+            else r.o = reinterpret_cast<float*>(tok + (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K);
+        } else if (BF16) {  // same layout rule, 16-bit elements
             uint16_t* tok = reinterpret_cast<uint16_t*>(page) + page_row_offset(s, g.K, kSegInp);
             r.a = reinterpret_cast<const float*>(tok);
             if (out_id == 1) r.o = g.q_output + (int64_t)b * g.N;  // q stays fp32

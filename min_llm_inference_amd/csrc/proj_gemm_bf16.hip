@@ -51,7 +51,9 @@ union Frag8 {
 };
 
 // MT = 32-row sub-tiles per wave (rows per workgroup = 64 * MT), KB = k extent of a staged tile (32 or 64)
-template <int MODE, int MT = 1, int KB = 32>
+// FP8 = the pages hold OCP e4m3 bytes (MLI_ELEM_FP8): A rows are widened to bf16 on their way into LDS (exact), K / V rows
+// leave as fp8 (round to nearest even, saturating); the weights are bf16 and everything between is the bf16 kernel
+template <int MODE, int MT = 1, int KB = 32, bool FP8 = false>
 __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     constexpr int HM = 64 * MT;              // shadows the namespace-level 64
     constexpr int HK = KB;
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
             if (m0 + tid < fill_total) {
                 int zz, ss;
                 fill_index_lookup(fill_index[0], kLatest ? g.B : g.n_new, m0 + tid, zz, ss);
-                r = kLatest ? resolve_row<MODE, true>(g, zz, 0, out_id) : resolve_row<MODE, true>(g, ss, zz, out_id);
+                r = kLatest ? resolve_row<MODE, true, FP8>(g, zz, 0, out_id) : resolve_row<MODE, true, FP8>(g, ss, zz, out_id);
             }
         } else {
-            r = resolve_row<MODE, true>(g, m0 + tid, z, out_id);
+            r = resolve_row<MODE, true, FP8>(g, m0 + tid, z, out_id);
         }
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
@@ -139,15 +141,32 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
                     const float4 e1 = *reinterpret_cast<const float4*>(e_src[p] + k0 + a_k8 + 4);
                     const float4 p0 = *reinterpret_cast<const float4*>(p_src[p] + k0 + a_k8);
                     const float4 p1 = *reinterpret_cast<const float4*>(p_src[p] + k0 + a_k8 + 4);
-                    uint4 x;
-                    x.x = f32_to_bf16(e0.x + p0.x) | ((uint32_t)f32_to_bf16(e0.y + p0.y) << 16);
-                    x.y = f32_to_bf16(e0.z + p0.z) | ((uint32_t)f32_to_bf16(e0.w + p0.w) << 16);
-                    x.z = f32_to_bf16(e1.x + p1.x) | ((uint32_t)f32_to_bf16(e1.y + p1.y) << 16);
-                    x.w = f32_to_bf16(e1.z + p1.z) | ((uint32_t)f32_to_bf16(e1.w + p1.w) << 16);
-                    a_reg[p] = x;
-                    if (writes_x) *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a_src[p]) + k0 + a_k8) = x;
+                    if constexpr (FP8) {   // x = fp8(emb[tok] + wpe[s]): fp32 sum, one rounding; the MFMA sees what the page holds
+                        const uint2 x8 = make_uint2(f32x4_to_fp8x4(e0.x + p0.x, e0.y + p0.y, e0.z + p0.z, e0.w + p0.w),
+                                                    f32x4_to_fp8x4(e1.x + p1.x, e1.y + p1.y, e1.z + p1.z, e1.w + p1.w));
+                        const uint2 lo = fp8x4_to_bf16x4(x8.x), hi = fp8x4_to_bf16x4(x8.y);
+                        a_reg[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        if (writes_x)
+                            *reinterpret_cast<uint2*>(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(a_src[p])) + k0 + a_k8) = x8;
+                    } else {
+                        uint4 x;
+                        x.x = f32_to_bf16(e0.x + p0.x) | ((uint32_t)f32_to_bf16(e0.y + p0.y) << 16);
+                        x.y = f32_to_bf16(e0.z + p0.z) | ((uint32_t)f32_to_bf16(e0.w + p0.w) << 16);
+                        x.z = f32_to_bf16(e1.x + p1.x) | ((uint32_t)f32_to_bf16(e1.y + p1.y) << 16);
+                        x.w = f32_to_bf16(e1.z + p1.z) | ((uint32_t)f32_to_bf16(e1.w + p1.w) << 16);
+                        a_reg[p] = x;
+                        if (writes_x) *reinterpret_cast<uint4*>(const_cast<uint16_t*>(a_src[p]) + k0 + a_k8) = x;
+                    }
                 }
-            } else if (a_src[p] != nullptr && k0 + a_k8 < g.K) a_reg[p] = *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8);
+            } else if (a_src[p] != nullptr && k0 + a_k8 < g.K) {
+                if constexpr (FP8) {   // 8 fp8 (8 bytes) -> 8 bf16
+                    const uint2 x8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a_src[p]) + k0 + a_k8);
+                    const uint2 lo = fp8x4_to_bf16x4(x8.x), hi = fp8x4_to_bf16x4(x8.y);
+                    a_reg[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    a_reg[p] = *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8);
+                }
+            }
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
@@ -240,6 +259,7 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
             float* op = o_ptr[mi];
             if (op != nullptr && n < g.N) {
                 if (out_id == 1) op[n] = acc[mt][r];                                         // q: fp32
+                else if (FP8) reinterpret_cast<uint8_t*>(op)[n] = (uint8_t)f32_to_fp8(acc[mt][r]);   // K / V: fp8 page rows
                 else reinterpret_cast<uint16_t*>(op)[n] = f32_to_bf16(acc[mt][r]);            // K / V: bf16 page rows
             }
         }
@@ -511,6 +531,52 @@ int launch_fill_paged_bf16_embed(const float* emb_table, const float* wpe, const
     dim3 grid(ceil_div_i(D, HN) * 2, ceil_div_i(S, HM), n_new);
     if (g.compact) grid = dim3(ceil_div_i(D, HN) * 2, ceil_div_i(S * n_new, HM), 1);
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedFill>), grid, dim3(kHThreads), 0, st, g);
+    return launch_status();
+}
+
+// ---- fp8 (OCP e4m3) pages, bf16 weights: MLI_ELEM_FP8 of the lean entry points --------------------------------------
+int launch_latest_paged_fp8(uint8_t* const* page_table, const int* lengths, const uint16_t* wk, const uint16_t* wq,
+                            const uint16_t* wv, float* q, int B, int S, int D, hipStream_t st) {
+    if (B <= 0 || S % kPage != 0 || D % 16 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wq);
+    g.w[2] = reinterpret_cast<const float*>(wv); g.n_out = 3;
+    g.out_id[0] = 0; g.out_id[1] = 1; g.out_id[2] = 2;
+    g.M = B; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.q_output = q; g.lengths = lengths;
+    g.B = B; g.S = S;
+    g.compact = latest_compact(B, D);
+    const int tiles_x = ceil_div_i(D, HN) * 3;
+    if (gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest, 2, 64, true>), dim3(tiles_x, ceil_div_i(B, 128), 1),
+                           dim3(kHThreads), 0, st, g);
+        return launch_status();
+    }
+    dim3 grid(tiles_x, ceil_div_i(B, HM), 1);
+    if (D >= 256 && D <= 1024 && deep_k_tiles_enabled())
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest, 1, 128, true>), grid, dim3(kHThreads), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedLatest, 1, 32, true>), grid, dim3(kHThreads), 0, st, g);
+    return launch_status();
+}
+
+// emb_table == nullptr: the x rows are read from segment 0 (fill only); else the encoder is the GEMM's prologue
+int launch_fill_paged_fp8_embed(const float* emb_table, const float* wpe, const int* tokens, uint8_t* const* page_table,
+                                const int* new_idx, const int* lengths, const uint16_t* wk, const uint16_t* wv, int B, int S,
+                                int D, int n_new, hipStream_t st) {
+    if (n_new == 0) return 0;
+    if (n_new < 0 || B <= 0 || S % kPage != 0 || D % 16 != 0) return MLI_ERR_BAD_ARG;
+    GemmArgs g{};
+    g.emb_table = emb_table; g.wpe = wpe; g.inp = tokens;
+    g.w[0] = reinterpret_cast<const float*>(wk); g.w[1] = reinterpret_cast<const float*>(wv); g.n_out = 2;
+    g.out_id[0] = 0; g.out_id[1] = 2;
+    g.M = S; g.N = D; g.K = D;
+    g.page_table = reinterpret_cast<float* const*>(page_table); g.lengths = lengths; g.new_batch_idx = new_idx;
+    g.B = B; g.S = S;
+    g.n_new = n_new; g.compact = fill_compact(n_new);
+    dim3 grid(ceil_div_i(D, HN) * 2, ceil_div_i(S, HM), n_new);
+    if (g.compact) grid = dim3(ceil_div_i(D, HN) * 2, ceil_div_i(S * n_new, HM), 1);
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<kPagedFill, 1, 32, true>), grid, dim3(kHThreads), 0, st, g);
     return launch_status();
 }
 

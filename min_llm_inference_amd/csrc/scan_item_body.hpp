@@ -157,7 +157,9 @@ __device__ __forceinline__ void row_publish_merge(float m, float l, float2* ml_r
 //   gate.wait_inputs(b)   all threads; returns once the row's projection is visible (agent acquire done, barrier passed);
 //                         K / V rows of OLDER pages are requested before it, q and the row's last page after it;
 //   gate.row_done(b)      thread 0 of the workgroup that wrote attention_result[b] (write-through, drained, barrier passed).
-template <class E, int NJ, bool NT, int TBR, int WAVES, bool DS, bool SCORES, class Gate>
+// RPI = token slots per load instruction (scan_common.hpp; 1 except for narrow fp8 rows): a batch is TBR instructions =
+//   TBR * RPI slots
+template <class E, int NJ, bool NT, int TBR, int WAVES, bool DS, bool SCORES, class Gate, int RPI = 1>
 __device__ __forceinline__ void fused_scan_item(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* ml, float* partial,
@@ -165,6 +167,8 @@ __device__ __forceinline__ void fused_scan_item(
     int slots, unsigned* arrivals, int b, int c, bool first_grid_row, int trace_stride, unsigned char* smem_raw, Gate gate) {
     constexpr int EPL = E::EPL;
     constexpr bool GATED = Gate::kGated;
+    constexpr int LPR = kWave / RPI;   // lanes per token row
+    static_assert(RPI == 1 || (NJ == 1 && !DS && !GATED), "several rows per instruction: rows of one lane load, whole pages per wave");
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
     float* red = reinterpret_cast<float*>(smem_raw + (size_t)(ct / kPage) * 8);            // [waves][NJ*64*EPL]
     __shared__ float2 wave_ml[WAVES];
@@ -194,13 +198,14 @@ __device__ __forceinline__ void fused_scan_item(
     float qr[NJ][EPLc];
     bool live[NJ];
     unsigned voff[NJ];
+    const int lane_u = lane % LPR, lane_grp = lane / LPR;   // unit inside the row, row inside the load instruction
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int u = (DS ? wave * NJ * kWave : 0) + lane + j * kWave;
+        const int u = (DS ? wave * NJ * kWave : 0) + lane_u + j * kWave;
         live[j] = u < Du;
         // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
         // them, so the loads need no per-lane predication
-        voff[j] = live[j] ? (unsigned)u * 16u : 0x40000000u;
+        voff[j] = live[j] ? (unsigned)u * 16u + (unsigned)lane_grp * (unsigned)(3 * D * E::kBytes) : 0x40000000u;
         if constexpr (!GATED) {
 #pragma unroll
             for (int e = 0; e < EPLc; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPLc + e] : 0.f;
@@ -278,7 +283,7 @@ __device__ __forceinline__ void fused_scan_item(
     // `pos` of every page lives in register buffer pos % 4, and before batch `pos` is consumed batch pos + 3 -- of
     // this page or of the wave's next page -- is issued, so three batches (24 KiB at bf16 D=512) stay in flight
     // per wave across the butterfly reduction, the softmax update and the page boundary.
-    constexpr int NB = 16 / TBR;
+    constexpr int NB = 16 / (TBR * RPI);
     constexpr int NPOS = 2 * NB;
     constexpr int PD = 3;
     fu_u32x4 buf[4][TBR][NJ];
@@ -299,12 +304,12 @@ __device__ __forceinline__ void fused_scan_item(
         // a null page (row longer than its pages: a caller bug) gets an empty range: its loads return zeros
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(upg), 0, upg != nullptr ? block_bytes : 0, 0x00020000);
-        const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * (int)row_bytes;
+        const int base = (pos < NB ? (int)seg_bytes : 2 * (int)seg_bytes) + (pos % NB) * TBR * RPI * (int)row_bytes;
 #pragma unroll
         for (int t = 0; t < TBR; ++t)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * (int)row_bytes, NT ? 2 : 0);
+                buf[bi][t][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], base + t * RPI * (int)row_bytes, NT ? 2 : 0);
     };
 
     constexpr int PSTEP = DS ? 1 : WAVES;
@@ -347,9 +352,9 @@ __device__ __forceinline__ void fused_scan_item(
         const bool has_next = pi + PSTEP < npages;
         const char* next = has_next ? page_ptr(pi + PSTEP) : nullptr;
         const int nt = min(kPage, ntok - pi * kPage);  // live tokens in this page (>= 1)
-        float sacc[16];
+        float sacc[16 / RPI];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sacc[t] = 0.f;
+        for (int t = 0; t < 16 / RPI; ++t) sacc[t] = 0.f;
         float p_lane = 0.f;
 
         static_for<NPOS>([&](auto POS) {
@@ -374,8 +379,8 @@ __device__ __forceinline__ void fused_scan_item(
                     }
                 if constexpr (pos == NB - 1) {
                     // all 16 slots scored (slots >= nt hold allocated but meaningless data: masked here)
-                    float tot = wave_reduce16(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15
-                    const int slot = (lane >> 2) & 15;
+                    float tot = rpi_reduce<RPI>(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15 (RPI = 1)
+                    const int slot = rpi_slot_of_lane<RPI>(lane);
                     if constexpr (DS) {
                         // complete the dot products across the waves' row slices (fixed order: identical in every wave)
                         float* xs = red + (pi & 1) * (WAVES * 16);
@@ -407,12 +412,17 @@ __device__ __forceinline__ void fused_scan_item(
 #pragma unroll
                 for (int t = 0; t < TBR; ++t) {
                     // the slot's probability sits in lane 4 * slot: broadcast through an SGPR
-                    const float p = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p_lane), 4 * (first + t)));
-                    if (first + t < nt) {  // wave-uniform: never multiply unwritten page memory, even by zero
+                    const float p = rpi_prob<RPI>(p_lane, first + t, lane);
+                    if (RPI * (first + t) < nt) {  // wave-uniform: never multiply unwritten page memory, even by zero
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
+                            fu_u32x4 raw = buf[bi][t][j];
+                            if constexpr (RPI > 1) {   // (per lane group: a slot beyond the row reads as zeros)
+                                const bool ok = RPI * (first + t) + lane_grp < nt;
+                                raw.x = ok ? raw.x : 0u; raw.y = ok ? raw.y : 0u; raw.z = ok ? raw.z : 0u; raw.w = ok ? raw.w : 0u;
+                            }
                             float vf[EPL];
-                            E::unpack(buf[bi][t][j], vf);
+                            E::unpack(raw, vf);
 #pragma unroll
                             for (int e = 0; e < EPL; ++e) acc[j][e] = fmaf(p, vf[e], acc[j][e]);
                         }
@@ -456,12 +466,15 @@ __device__ __forceinline__ void fused_scan_item(
             }
         }
     } else {
-        constexpr int kRowF = NJ * kWave * EPL;  // floats one wave contributes
+        constexpr int kRowF = NJ * LPR * EPL;  // floats one wave contributes
         if (lane == 0) wave_ml[wave] = make_float2(run_m, run_l);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) red[wave * kRowF + (j * kWave + lane) * EPL + e] = acc[j][e];
+            for (int e = 0; e < EPL; ++e) {
+                const float a = rpi_group_sum<RPI>(acc[j][e]);   // the lane groups hold different slots' contributions
+                if (RPI == 1 || lane < LPR) red[wave * kRowF + (j * kWave + lane_u) * EPL + e] = a;
+            }
         __syncthreads();
         m = -INFINITY;
 #pragma unroll

@@ -10,6 +10,7 @@ import numpy as np
 from ._lib import EngineConfig, EngineStats, MliError, load_library
 
 CONTIGUOUS, PAGED, PAGED_GEMM, PAGED_BF16 = 0, 1, 2, 3  # PAGED_BF16: extension, bf16 pages and weights
+PAGED_FP8 = 4  # extension, opt-in: fp8 (OCP e4m3) pages, bf16 weights
 
 
 def _fp(a):

@@ -21,6 +21,7 @@
 #include <functional>
 
 #include "bf16_extension.h"
+#include "fp8_extension.h"
 #include "inferencer.h"
 
 // (inp, lengths, new_item_indices, decoder_result, n_new_items): one forward of any paged model
@@ -43,6 +44,12 @@ void start_paged_attention_cublas_inference_engine_pipelined(
     const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
     ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
     PagedAttentionsManager& paged_attention_manager, PagedAttentionCublasInferenceModel& inference_model,
+    size_t n_batch_size, size_t n_sequence, int n_forward_rounds = 1);
+
+void start_paged_attention_fp8_inference_engine_pipelined(
+    const TensorFloat& emb_table, const TensorFloat& pos_table, ItemStorage& item_storage,
+    ProcessingStorage& processing_storage, MemoryBlockManager& memory_block_manager,
+    PagedAttentionsManager& paged_attention_manager, PagedAttentionFp8InferenceModel& inference_model,
     size_t n_batch_size, size_t n_sequence, int n_forward_rounds = 1);
 
 void start_paged_attention_bf16_inference_engine_pipelined(

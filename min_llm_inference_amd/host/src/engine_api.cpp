@@ -12,6 +12,7 @@
 
 #include "bf16_extension.h"
 #include "constants.h"
+#include "fp8_extension.h"
 #include "inference_model.h"
 #include "inferencer.h"
 #include "mli_engine.h"
@@ -42,6 +43,7 @@ struct mli_engine {
     std::unique_ptr<PagedAttentionInferenceModel> paged_model;
     std::unique_ptr<PagedAttentionCublasInferenceModel> gemm_model;
     std::unique_ptr<PagedAttentionBf16InferenceModel> bf16_model;
+    std::unique_ptr<PagedAttentionFp8InferenceModel> fp8_model;
     std::unique_ptr<MemoryBlockManager> pool;
     std::unique_ptr<PagedAttentionsManager> pages;
     TensorInt inp_device, inp_host, lengths_device, lengths_host, new_idx_device, new_idx_host;
@@ -100,6 +102,16 @@ struct mli_engine {
             bf16_model = std::make_unique<PagedAttentionBf16InferenceModel>(
                 PagedAttentionBf16Layer(make_device_bf16(wk, {D, D}), make_device_bf16(wq, {D, D}),
                                         make_device_bf16(wv, {D, D}), B, D, S),
+                B, S, D, V, c.n_forward_rounds);
+            init_loop_tensors(B, S);
+            return;
+        }
+        if (c.kind == MLI_ENGINE_PAGED_FP8) {
+            pool = std::make_unique<MemoryBlockManager>(c.n_blocks, fp8_page_block_floats(D));
+            pages = std::make_unique<PagedAttentionsManager>(B, S, D);
+            fp8_model = std::make_unique<PagedAttentionFp8InferenceModel>(
+                PagedAttentionFp8Layer(make_device_bf16(wk, {D, D}), make_device_bf16(wq, {D, D}),
+                                       make_device_bf16(wv, {D, D}), B, D, S),
                 B, S, D, V, c.n_forward_rounds);
             init_loop_tensors(B, S);
             return;
@@ -177,6 +189,9 @@ struct mli_engine {
                 else if (cfg.kind == MLI_ENGINE_PAGED_BF16)
                     bf16_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
                                         pages->get_page_table_device());
+                else if (cfg.kind == MLI_ENGINE_PAGED_FP8)
+                    fp8_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
+                                       pages->get_page_table_device());
                 else
                     gemm_model->forward(inp, lengths, new_idx, result, n_new, emb_table, pos_table,
                                         pages->get_page_table_device(), handle);
@@ -201,6 +216,9 @@ struct mli_engine {
         else if (cfg.kind == MLI_ENGINE_PAGED_BF16)
             bf16_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                 pos_table, pages->get_page_table_device());
+        else if (cfg.kind == MLI_ENGINE_PAGED_FP8)
+            fp8_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
+                               pos_table, pages->get_page_table_device());
         else
             gemm_model->forward(inp_device, lengths_device, new_idx_device, result_device, n_new_items, emb_table,
                                 pos_table, pages->get_page_table_device(), handle);
@@ -253,7 +271,8 @@ const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
 int mli_engine_create(const mli_engine_config* c, const float* emb_table, const float* pos_table, const float* wk,
                       const float* wq, const float* wv, mli_engine** out) {
     if (!c || !out || !emb_table || !pos_table || !wk || !wq || !wv) { g_last_error = "null argument"; return -1; }
-    if (c->kind < 0 || c->kind > 3 || (c->kind == MLI_ENGINE_PAGED_BF16 && c->emb_dim % 8) || c->n_batch <= 0 || c->n_sequence <= 0 || c->emb_dim <= 0 || c->emb_dim % 4 ||
+    if (c->kind < 0 || c->kind > MLI_ENGINE_PAGED_FP8 || (c->kind == MLI_ENGINE_PAGED_BF16 && c->emb_dim % 8) ||
+        (c->kind == MLI_ENGINE_PAGED_FP8 && (c->emb_dim % 16 || c->emb_dim > 2048)) || c->n_batch <= 0 || c->n_sequence <= 0 || c->emb_dim <= 0 || c->emb_dim % 4 ||
         c->n_vocab <= EOF_TOKEN_ID ||
         (c->kind != MLI_ENGINE_CONTIGUOUS && (c->n_sequence % PAGE_BLOCK_SIZE || c->n_blocks <= 0 ||
                                               c->n_forward_rounds < 1 || c->n_forward_rounds > PAGE_BLOCK_SIZE)) ||

@@ -7,6 +7,7 @@
 
 #include "bf16_extension.h"
 #include "constants.h"
+#include "fp8_extension.h"
 #include "pipelined_engine.h"
 #include "runtime.h"
 #include "throughput_counter.h"
@@ -171,6 +172,27 @@ void start_paged_attention_bf16_inference_engine(const TensorFloat& emb_table, c
         start_paged_attention_bf16_inference_engine_pipelined(emb_table, pos_table, item_storage, processing_storage,
                                                               memory_block_manager, paged_attention_manager,
                                                               inference_model, n_batch_size, n_sequence, n_forward_rounds);
+        return;
+    }
+    run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,
+                     n_sequence, n_forward_rounds, [&](LoopTensors& t, int n_new_items) {
+                         inference_model.forward(t.inp_device, t.lengths_device, t.new_items_indices_device,
+                                                 t.decoder_result_device, n_new_items, emb_table, pos_table,
+                                                 paged_attention_manager.get_page_table_device());
+                     });
+}
+
+// EXTENSION, opt-in (no reference counterpart): the same loop over fp8 (OCP e4m3) pages and bf16 weights.
+void start_paged_attention_fp8_inference_engine(const TensorFloat& emb_table, const TensorFloat& pos_table,
+                                                ItemStorage& item_storage, ProcessingStorage& processing_storage,
+                                                MemoryBlockManager& memory_block_manager,
+                                                PagedAttentionsManager& paged_attention_manager,
+                                                PagedAttentionFp8InferenceModel& inference_model, size_t n_batch_size,
+                                                size_t n_sequence, int n_forward_rounds) {
+    if (pipelined_loop_applies(paged_attention_manager, n_forward_rounds)) {
+        start_paged_attention_fp8_inference_engine_pipelined(emb_table, pos_table, item_storage, processing_storage,
+                                                             memory_block_manager, paged_attention_manager,
+                                                             inference_model, n_batch_size, n_sequence, n_forward_rounds);
         return;
     }
     run_paged_engine(item_storage, processing_storage, memory_block_manager, paged_attention_manager, n_batch_size,

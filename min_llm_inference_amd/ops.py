@@ -16,7 +16,14 @@ PAGE_BLOCK_SIZE = 16
 EMPTY_ROW_TOKEN_ID = -1
 EOF_TOKEN_ID = 1023
 
+ELEM_F32, ELEM_BF16, ELEM_FP8 = 0, 1, 2  # MLI_ELEM_* of include/mli_kernels.h
+
 _workspaces = {}
+
+
+def has_fp8():
+    """Whether this build of the library implements the fp8 (OCP e4m3) page extension."""
+    return bool(load_library().mli_elem_supported(ELEM_FP8))
 
 
 def _p(t):
@@ -261,25 +268,30 @@ def decode_scan_paged(q_output, page_table, lengths, qkt_output, attention_resul
                                                 need, _stream()), "mli_decode_scan_paged")
 
 
+def _elem_of(wk, elem):
+    """MLI_ELEM_* of the pages: given, or from the weights' dtype (fp8 pages come with bf16 weights: say so)."""
+    return int(wk.dtype == torch.bfloat16) if elem is None else int(elem)
+
+
 def paged_attention_lean(page_table, lengths, wk, wq, wv, new_batch_idx, q_output, attention_result, n_new_items,
-                         n_sequence):
+                         n_sequence, elem=None):
     """What the attention layers run: the paged composition without materialising scores / probabilities
-    (mli_paged_attention_lean); page / weight element type from the weights' dtype."""
+    (mli_paged_attention_lean); page element type = elem (ELEM_*), default from the weights' dtype."""
     B = page_table.shape[0]
     D = wk.shape[0]
     ws, need = workspace_for(B, n_sequence, D, q_output.device)
     _check(load_library().mli_paged_attention_lean(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv),
                                                    _p(new_batch_idx), _p(q_output), _p(attention_result), B, n_sequence,
-                                                   D, n_new_items, int(wk.dtype == torch.bfloat16), _p(ws), need,
+                                                   D, n_new_items, _elem_of(wk, elem), _p(ws), need,
                                                    _stream()), "mli_paged_attention_lean")
 
 
-def paged_prefill(emb_table, wpe, inp, page_table, lengths, new_item_indices, wk, wv, n_new_items):
-    """Encoder + prefill fill in one launch (mli_paged_prefill); element type from the weights' dtype."""
+def paged_prefill(emb_table, wpe, inp, page_table, lengths, new_item_indices, wk, wv, n_new_items, elem=None):
+    """Encoder + prefill fill in one launch (mli_paged_prefill); page element type = elem, default from the weights."""
     B, S = inp.shape
     _check(load_library().mli_paged_prefill(_p(emb_table), _p(wpe), _p(inp), _p(page_table), _p(lengths),
                                             _p(new_item_indices), _p(wk), _p(wv), B, S, emb_table.shape[1], n_new_items,
-                                            int(wk.dtype == torch.bfloat16), _stream()), "mli_paged_prefill")
+                                            _elem_of(wk, elem), _stream()), "mli_paged_prefill")
 
 
 def prefill(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices, wk, wv, kt_cache, v_cache, n_new_items):
@@ -418,3 +430,19 @@ def stream_copy(src, dst):
 
 def stream_read(src, sink):
     _check(load_library().mli_stream_read(_p(src), _p(sink), src.numel(), _stream()), "mli_stream_read")
+
+
+def f32_to_fp8(src, dst=None):
+    """float32 tensor -> uint8 tensor of OCP e4m3 codes with the kernels' own conversion (mli_f32_to_fp8)."""
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+    _check(load_library().mli_f32_to_fp8(_p(src), _p(dst), src.numel(), _stream()), "mli_f32_to_fp8")
+    return dst
+
+
+def get_latest_k_q_v_paged_lean(page_table, lengths, wk, wq, wv, q_output, n_sequence, elem=None):
+    """The decode projection for any page element type (mli_get_latest_k_q_v_paged_lean)."""
+    B = page_table.shape[0]
+    _check(load_library().mli_get_latest_k_q_v_paged_lean(_p(page_table), _p(lengths), _p(wk), _p(wq), _p(wv), _p(q_output), B,
+                                                          n_sequence, wq.shape[0], _elem_of(wk, elem), _stream()),
+           "mli_get_latest_k_q_v_paged_lean")

@@ -31,12 +31,13 @@ class CpuEngine:
 
     def __init__(self, oracle, model, items, n_batch, n_sequence, bf16=False):
         """bf16 = True models the bf16 page extension: Wk/Wq/Wv and everything stored in a page (input embedding, K,
-        V) are rounded to bfloat16 where the GPU path stores them; q, scores, sums and logits stay fp32."""
+        V) are rounded to bfloat16 where the GPU path stores them; q, scores, sums and logits stay fp32.
+        bf16 = "fp8" models the fp8 page extension: bf16 weights, page contents rounded to OCP e4m3 (saturating)."""
         self.o, self.m = oracle, dict(model)
-        self.bf16 = bf16
+        self.bf16 = bool(bf16)
         if bf16:
-            from helpers import bf16_round
-            self.round = bf16_round
+            from helpers import bf16_round, fp8_round
+            self.round = fp8_round if bf16 == "fp8" else bf16_round
             for k in ("wk", "wq", "wv"):
                 self.m[k] = bf16_round(model[k])
         D = model["wk"].shape[0]

@@ -166,6 +166,47 @@ def bf16_bits(x):
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
+_FP8_TABLE = None
+
+
+def _fp8_table():
+    """The 127 non-negative finite OCP e4m3fn values, indexed by their byte code 0x00 .. 0x7e (0x7f is NaN):
+    e = 0: m * 2^-9 (subnormal), else (1 + m / 8) * 2^(e - 7); largest 448."""
+    global _FP8_TABLE
+    if _FP8_TABLE is None:
+        codes = np.arange(127)
+        e, m = codes >> 3, codes & 7
+        _FP8_TABLE = np.where(e == 0, m * 2.0 ** -9, (1 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7)).astype(np.float64)
+    return _FP8_TABLE
+
+
+def fp8_bits(x):
+    """float32 -> OCP e4m3fn byte codes (uint8): round to nearest, ties to the even code, SATURATING at +-448 (the
+    format has no infinity; the kernels clamp before v_cvt_pk_fp8_f32, which would give NaN from 465 on), NaN -> 0x7f."""
+    x = np.ascontiguousarray(x, np.float32)
+    t = _fp8_table()
+    a = np.minimum(np.abs(x.astype(np.float64)), 448.0)
+    hi = np.clip(np.searchsorted(t, a, side="left"), 0, 126)          # first code with value >= a
+    lo = np.maximum(hi - 1, 0)
+    d_hi, d_lo = t[hi] - a, a - t[lo]
+    code = np.where(d_hi < d_lo, hi, np.where(d_lo < d_hi, lo, np.where(hi % 2 == 0, hi, lo)))
+    code = np.where(np.isnan(x), 0x7f, code).astype(np.uint8)
+    return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
+
+
+def fp8_decode(bits):
+    """OCP e4m3fn byte codes -> float32."""
+    b = np.asarray(bits, np.uint8)
+    mag = b & 0x7f
+    v = np.where(mag == 0x7f, np.nan, _fp8_table()[np.minimum(mag, 126)])
+    return np.where(b & 0x80, -v, v).astype(np.float32)
+
+
+def fp8_round(x):
+    """float32 values rounded to the nearest OCP e4m3fn value (saturating), returned as float32."""
+    return fp8_decode(fp8_bits(x)).reshape(np.shape(x))
+
+
 def bf16_round(x):
     """float32 values rounded to the nearest bfloat16, returned as float32."""
     return (bf16_bits(x).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(x))

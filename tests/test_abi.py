@@ -39,7 +39,7 @@ def test_arity_matches_header():
 
 
 def test_abi_version_and_workspace_query(mli):
-    assert mli.mli_abi_version() == 3
+    assert mli.mli_abi_version() == 4
     # [row arrival counters: 64 KiB, fixed][chunk statistics, padded to 256 bytes][partial sums]
     assert mli.mli_attention_workspace_bytes(4, 64, 64) == 65536 + 256   # single chunk: no partial sums
     assert mli.mli_attention_workspace_bytes(1024, 4096, 512) == 65536 + 1024 * 64 * 8 + 1024 * 64 * 512 * 4

@@ -49,3 +49,9 @@ def test_two_ranks_share_the_gpu_over_gloo():
                 "--no-cpu-baseline", "--no-roofline"], timeout=600)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert out["config"]["rows_per_gpu"] == 256 and out["scaling"] == "weak"
+    # the N > 1 line proves what the collective saw
+    coll = out["collective"]
+    assert coll["backend"].startswith("gloo") and coll["ranks_seen"] == 2
+    assert coll["gathered_token_ids"] == 2 * 256 and coll["gathered_token_ids_valid"] == 2 * 256
+    assert coll["gather_us_per_step"] > 0 and coll["ms_per_step_without_gather"] > 0
+    assert out["repeat"]["regions"] >= 1 and out["config"]["rows_total"] == 512

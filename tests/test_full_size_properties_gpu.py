@@ -43,10 +43,15 @@ def _rows_from_pages(wl, rows, seg):
     """[len(rows), S, D] fp32 copy of segment `seg` of the given batch rows (zeros where no page is allocated)."""
     out = torch.zeros(len(rows), wl.S, wl.D, device=wl.dev)
     pv = _pool_view(wl)
+    lut = None
+    if pv.dtype == torch.uint8:   # fp8 pages: OCP e4m3 codes, decoded through the numpy model's table
+        from helpers import fp8_decode
+        lut = torch.from_numpy(fp8_decode(np.arange(256, dtype=np.uint8))).to(wl.dev)
     for i, b in enumerate(rows):
         ids = wl.page_ids[b]
         n = int((ids >= 0).sum())
-        out[i, :n * PAGE] = pv[torch.from_numpy(ids[:n]).to(wl.dev), :, seg, :].reshape(n * PAGE, wl.D).float()
+        raw = pv[torch.from_numpy(ids[:n]).to(wl.dev), :, seg, :].reshape(n * PAGE, wl.D)
+        out[i, :n * PAGE] = raw.float() if lut is None else lut[raw.long()]
     return out
 
 
@@ -174,6 +179,70 @@ def test_config4_default_lean_step_matches_the_oracle_on_128_rows(oracle, mli, c
         best = logits.max(axis=1)
         assert (logits[idx, tok[part]] >= best - 1e-3).all(), "decoder token = an argmax of the oracle's logits (1e-3)"
     assert worst < 1e-3
+
+
+def test_config4_fp8_lean_step_matches_the_oracle_on_128_rows(oracle, mli, dev):
+    """BASELINE config 4's shape with fp8 (OCP e4m3) pages -- the opt-in extension bench.py reports as configs.c4_fp8: the
+    lean step (projection from fp8 x rows, equal-shares scan with two token slots per load instruction, fused decoder
+    head) against the oracle on >= 128 rows (shortest, longest, rows cut by share boundaries).  Dead K / V slots are NaN
+    bytes (0x7f).  Unpinned by the reference (fp32 only): the oracle runs in fp32 on what the pages hold."""
+    from helpers import fp8_round
+    wl = _workload("c4", dev, "fp8")
+    try:
+        pid = torch.from_numpy(wl.page_ids).to(wl.dev)
+        s = (torch.arange(wl.S // PAGE, device=wl.dev)[:, None] * PAGE + torch.arange(PAGE, device=wl.dev)[None, :])
+        live = s[None, :, :] < wl.lengths[:, None, None]
+        ok = pid >= 0
+        dead = torch.ones(_pool_view(wl).shape[0], PAGE, dtype=torch.bool, device=wl.dev)
+        dead[pid[ok]] = ~live[ok]
+        _pool_view(wl)[:, :, 1:, :][dead] = 0x7f                              # K and V of every dead slot: NaN
+        L = wl.lengths_host.astype(np.int64)
+        cut, dyn = _share_boundary_rows(L)
+        rows = {int(np.argmin(L)), int(np.argmax(L))}
+        rows.update(int(b) for b in cut[:: max(1, len(cut) // 70)])
+        rows.update(int(b) for b in dyn[:: max(1, len(dyn) // 24)])
+        rows.update(range(0, wl.B, wl.B // 40))
+        rows = sorted(rows)
+        assert len(rows) >= 128
+        wl.attention_result.fill_(-7.0)
+        wl.lean_step()
+        torch.cuda.synchronize()
+        got = wl.attention_result.cpu().numpy()
+        got_q = wl.q_output.cpu().numpy()
+        tok = wl.decoder_result.view(-1).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert (wl.lengths.cpu().numpy() == wl.lengths_host + 1).all()
+        w = [t.float().cpu().numpy() for t in (wl.wk, wl.wq, wl.wv)]
+        emb = wl.emb_table.cpu().numpy()
+        for i0 in range(0, len(rows), 32):
+            part = rows[i0:i0 + 32]
+            x = _rows_from_pages(wl, part, 0).cpu().numpy()
+            k = _rows_from_pages(wl, part, 1).cpu().numpy()
+            v = _rows_from_pages(wl, part, 2).cpu().numpy()
+            Lp = wl.lengths_host[part].copy()
+            for i in range(len(part)):
+                x[i, Lp[i]:] = 0; k[i, Lp[i]:] = 0; v[i, Lp[i]:] = 0
+            kt = np.ascontiguousarray(k.transpose(0, 2, 1))
+            q = np.zeros((len(part), wl.D), np.float32)
+            oracle.get_latest_kt_q_v(x, Lp, w[0], w[1], w[2], kt, v, q)
+            idx = np.arange(len(part))
+            # the appended rows: what the step stored is the oracle's projection up to one fp8 step (2^-3 relative)
+            assert_close(k[idx, Lp - 1], fp8_round(kt[idx, :, Lp - 1]), thr=0.13, what="appended K rows vs oracle projection")
+            kt[idx, :, Lp - 1] = k[idx, Lp - 1]                                # the scan reads what the GPU stored
+            v[idx, Lp - 1] = _rows_from_pages(wl, part, 2).cpu().numpy()[idx, Lp - 1]
+            assert_close(got_q[part], q, what="q_output")
+            sc = np.zeros((len(part), wl.S), np.float32)
+            o = np.zeros((len(part), wl.D), np.float32)
+            oracle.qkt_host(q, kt, Lp, sc)
+            oracle.softmax_in_place_with_lengths_host(sc, Lp)
+            oracle.softmax_v_host(sc, v, o, Lp)
+            assert_close(got[part], o, what="attention_result of the fp8 lean step vs oracle")
+            logits = oracle.gemm_transpose_host(np.ascontiguousarray(o), emb)
+            best = logits.max(axis=1)
+            assert (logits[idx, tok[part]] >= best - 1e-3).all(), "decoder token = an argmax of the oracle's logits (1e-3)"
+    finally:
+        del wl
+        torch.cuda.empty_cache()
 
 
 def test_config4_repeat_is_bit_identical_and_forms_agree(mli, c4):
