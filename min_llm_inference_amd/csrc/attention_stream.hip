@@ -48,8 +48,8 @@ size_t stats_region_bytes_for(int B, int S);
 // MAXSEG = segments (rows touched) a workgroup finishes per group: their wave partials wait in LDS for the group's merge
 // RPI = token slots per load instruction (scan_common.hpp; 1 for the reference's fp32 and for bf16), TBR = load
 // instructions per batch: a batch covers TBR * RPI slots, a page is 2 * 16 / (TBR * RPI) batches
-template <class E, int NJ, bool NT, int TBR, int MAXSEG, int RPI = 1, int WGS = 2>
-__global__ __launch_bounds__(kStThreads, WGS) void fused_decode_stream_kernel(
+template <class E, int NJ, bool NT, int TBR, int MAXSEG, int RPI = 1>
+__global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ out, float2* ml, float* partial, unsigned* arrivals, unsigned* ticket, int B, int S, int D,
     int ml_per_row, int max_pages_wg, int dyn_pct, int gran) {
@@ -281,12 +281,7 @@ __global__ __launch_bounds__(kStThreads, WGS) void fused_decode_stream_kernel(
 #pragma unroll
                     for (int t = 0; t < TBR; ++t)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            float kf[EPL];
-                            E::unpack(buf[bi][t][j], kf);
-#pragma unroll
-                            for (int e = 0; e < EPL; ++e) sacc[pos * TBR + t] = fmaf(qr[j][e], kf[e], sacc[pos * TBR + t]);
-                        }
+                        for (int j = 0; j < NJ; ++j) ElemMath<E>::dot(buf[bi][t][j], qr[j], sacc[pos * TBR + t]);
                     if constexpr (pos == NB - 1) {
                         const float tot = rpi_reduce<RPI>(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15 (RPI = 1)
                         const int slot = rpi_slot_of_lane<RPI>(lane);
@@ -316,10 +311,7 @@ __global__ __launch_bounds__(kStThreads, WGS) void fused_decode_stream_kernel(
                                     const bool ok = RPI * (first + t) + lane_grp < nt;
                                     raw.x = ok ? raw.x : 0u; raw.y = ok ? raw.y : 0u; raw.z = ok ? raw.z : 0u; raw.w = ok ? raw.w : 0u;
                                 }
-                                float vf[EPL];
-                                E::unpack(raw, vf);
-#pragma unroll
-                                for (int e = 0; e < EPL; ++e) acc[j][e] = fmaf(p, vf[e], acc[j][e]);
+                                ElemMath<E>::axpy(raw, p, acc[j]);
                             }
                         }
                     }
@@ -524,6 +516,9 @@ int launch_stream_decode(const float* q, const void* const* page_table, const in
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    // Two workgroups per CU.  (Tried for the fp8 kernel at emb_dim 512, whose batches are half as many bytes as the bf16
+    // kernel's: three / four workgroups per CU under __launch_bounds__(256, 3 / 4) -- 168 / 128 VGPRs, 57 / 134 of them
+    // spilled -- 543 / 894 us against 338; decoding and multiplying in pairs (v_pk_fma_f32): 338.8 against 338.0 us.)
     const int G = 2 * n_cu;
     const int ml_per_row = ceil_div_i(S, 64);
     const size_t stats_bytes = stats_region_bytes_for(B, S);

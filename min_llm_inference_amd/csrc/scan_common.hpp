@@ -25,7 +25,23 @@ __device__ __forceinline__ fu_u32x4 fu_ldg(const void* p) {
     return *(fu_gu4_ptr)(p);
 }
 
-// one 16-byte lane load holds EPL elements
+// one 16-byte lane load holds EPL elements.  dot: s += q . (the load's elements); axpy: acc += p * (the load's elements)
+template <class E>
+struct ElemMath {
+    static __device__ __forceinline__ void dot(const fu_u32x4& r, const float (&q)[E::EPL], float& s) {
+        float f[E::EPL];
+        E::unpack(r, f);
+#pragma unroll
+        for (int e = 0; e < E::EPL; ++e) s = fmaf(q[e], f[e], s);
+    }
+    static __device__ __forceinline__ void axpy(const fu_u32x4& r, float p, float (&acc)[E::EPL]) {
+        float f[E::EPL];
+        E::unpack(r, f);
+#pragma unroll
+        for (int e = 0; e < E::EPL; ++e) acc[e] = fmaf(p, f[e], acc[e]);
+    }
+};
+
 struct ElemF32 {
     static constexpr int EPL = 4;
     static constexpr int kBytes = 4;

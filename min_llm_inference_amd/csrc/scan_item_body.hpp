@@ -371,12 +371,7 @@ __device__ __forceinline__ void fused_scan_item(
 #pragma unroll
                 for (int t = 0; t < TBR; ++t)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        float kf[EPL];
-                        E::unpack(buf[bi][t][j], kf);
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) sacc[pos * TBR + t] = fmaf(qr[j][e], kf[e], sacc[pos * TBR + t]);
-                    }
+                    for (int j = 0; j < NJ; ++j) ElemMath<E>::dot(buf[bi][t][j], qr[j], sacc[pos * TBR + t]);
                 if constexpr (pos == NB - 1) {
                     // all 16 slots scored (slots >= nt hold allocated but meaningless data: masked here)
                     float tot = rpi_reduce<RPI>(sacc, lane);  // lane holds the sum for slot (lane >> 2) & 15 (RPI = 1)
@@ -421,10 +416,7 @@ __device__ __forceinline__ void fused_scan_item(
                                 const bool ok = RPI * (first + t) + lane_grp < nt;
                                 raw.x = ok ? raw.x : 0u; raw.y = ok ? raw.y : 0u; raw.z = ok ? raw.z : 0u; raw.w = ok ? raw.w : 0u;
                             }
-                            float vf[EPL];
-                            E::unpack(raw, vf);
-#pragma unroll
-                            for (int e = 0; e < EPL; ++e) acc[j][e] = fmaf(p, vf[e], acc[j][e]);
+                            ElemMath<E>::axpy(raw, p, acc[j]);
                         }
                     }
                 }
