@@ -89,17 +89,22 @@ int mli_engine_decoder_result(mli_engine* engine, void** device_ptr, int* count)
 /* Finished item `index` (0 <= index < stats.finished), in completion order: id and tokens (prompt + generated). */
 int mli_engine_get_finished(mli_engine* engine, int index, int* id, int* tokens, int capacity, int* n_tokens);
 
-/* Process-wide: 1 (default) = the models' layers run the lean compositions (prefill with the encoder as the fill GEMM's
+/* The DEFAULT of engines created afterwards (every engine keeps its own value, see mli_engine_configure; two engines in one
+ * process never change each other's composition): 1 (default) = the models' layers run the lean compositions (prefill with the encoder as the fill GEMM's
  * prologue, attention without materialised scores / probabilities, decoder head with the argmax as the logits GEMM's
  * epilogue), 0 = the reference's launch sequence (encoder, fill, latest, scan + combine, logits, argmax).  Tokens are
  * identical either way; the switch exists to measure one against the other. */
 void mli_engine_set_lean_layers(int enabled);
 
-/* Process-wide: 1 = the models replay their pure decode forwards (no newly inserted rows) from a hipGraph recorded on
+/* The DEFAULT of engines created afterwards: 1 = the models replay their pure decode forwards (no newly inserted rows) from a hipGraph recorded on
  * the first such forward -- one host call per forward instead of one per launch (host/include/step_graph.h).  Only
  * engines with a private stream can record (the legacy default stream cannot be captured); others keep launching
  * eagerly.  Default 0: a replay costs the GPU a few microseconds more than the same launches issued from C++. */
 void mli_engine_set_step_graphs(int enabled);
+
+/* This engine's own switches, before its first step / run: lean_layers and step_graphs as above; -1 leaves a value as
+ * it is.  (The fp8 engine has the lean compositions only.) */
+int mli_engine_configure(mli_engine* engine, int lean_layers, int step_graphs);
 
 const char* mli_engine_last_error(void);
 

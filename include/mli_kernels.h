@@ -307,12 +307,7 @@ int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float*
  * call (the Python test / bench front end); the C++ layers issue the same launches themselves.
  *   paged:      q_output [n_batch, emb_dim] is scratch; attention_result [n_batch, emb_dim] holds the attention output
  *   contiguous: qkt_output [n_batch, n_sequence] is scratch for the shapes mli_self_attention_lean does not cover
- * With mli_tune "step_fused" = 1, small fp32 paged batches (both GEMMs of the step are the panel kernel's shapes and the
- * scan runs the chunked grid with the in-kernel merge, e.g. BASELINE config 3) run the step as ONE launch whose workgroups
- * take the four kernels' bodies as roles -- projection tiles, scan items, logits tiles, token pick -- and hand rows to
- * each other through counters in the workspace (decode_step_fused.hip).  Results are bit-identical either way; measured
- * slower than the separate launches (config 3: 72 vs 67 us), hence off by default.  The workspace must have been
- * initialised once (mli_attention_workspace_init). */
+ * The workspace must have been initialised once (mli_attention_workspace_init). */
 int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk, const void* wq, const void* wv,
                           const float* emb_table, const float* wpe_table, float* q_output, float* attention_result,
                           int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
@@ -325,11 +320,6 @@ int mli_decode_step(float* inp_embedding, int* lengths, const float* wk, const f
                     int n_batch, int n_sequence, int emb_dim, int n_vocab,
                     void* workspace, size_t workspace_bytes, void* decoder_scratch, size_t decoder_scratch_bytes,
                     void* stream);
-
-/* Diagnostic: the error word of the one-launch step kept in `workspace` (0 = every in-launch wait so far ended normally;
- * 1 / 2 / 3 = a scan item / a logits tile / a token-pick workgroup gave up waiting: the step's results are then
- * undefined).  Synchronises the device; never called by the product path. */
-int mli_debug_step_fused_error(void* workspace, size_t workspace_bytes, unsigned* code_out);
 
 /* ------------------------------------------------------------------------------------
  * hipGraph capture of a decode step.  No entry point above allocates or synchronises, so any sequence of them issued
@@ -363,7 +353,8 @@ int mli_clone_inp_embedding_k_v_cache(float* const* page_table, const float* inp
  * use: n (a multiple of 4) values.  For building synthetic fp8 pages in tests and bench.py. */
 int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream);
 
-/* Tuning / diagnostic knobs (process-wide; results are identical for every setting):
+/* Tuning / diagnostic knobs.  PER THREAD: a setting applies to the launches the calling thread issues afterwards, so a test
+ * or a probe never changes what an engine on another thread runs (results are identical for every setting):
  *   "chunk_tokens"     0 = heuristic, else a power of two in [64, 1024]: tokens per workgroup of the
  *                      split-sequence kernels
  *   "nt_loads"         non-temporal hint on the K/V stream: 2 (default) = where the rows' K/V (n_batch * n_sequence *
@@ -409,8 +400,6 @@ int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream);
  *                      multiplying, when the reduction is >= 256 long; 0 = one wave does both (identical results)
  *   "gemm_bf16_split"  1 (default) = the bf16 decode projection of a large batch (>= 1024 rows, emb_dim >= 1024, a multiple
  *                      of 128) runs the loader-wave / MFMA-wave kernel, 0 = the 128 x 64 tiled kernel (identical results)
- *   "step_fused"       1 = mli_paged_decode_step runs small fp32 paged batches as one launch (decode_step_fused.hip),
- *                      0 (default) = always the separate launches
  *   "gemm_panel"       1 (default) = small fp32 products (emb_dim <= 512, fewer than 256 tiles of 64x64: the decode
  *                      projection and the logits of configs 2 / 3) run the latency-shaped kernel (32x32 tiles, the
  *                      whole K panel requested at once), 0 = always the tiled kernel, 2 = whenever the shape allows

@@ -74,7 +74,6 @@ SIGNATURES = {
     "mli_prefill": [_P] * 10 + [_I] * 5 + [_P],
     "mli_paged_decode_step": [_P] * 10 + [_I] * 7 + [_P, _Z, _P, _Z, _P],
     "mli_decode_step": [_P] * 13 + [_I] * 4 + [_P, _Z, _P, _Z, _P],
-    "mli_debug_step_fused_error": [_P, _Z, ctypes.POINTER(ctypes.c_uint)],
     "mli_graph_begin_capture": [_P],
     "mli_graph_end_capture": [_P, ctypes.POINTER(ctypes.c_void_p)],
     "mli_graph_launch": [_P, _P],
@@ -115,6 +114,7 @@ ENGINE_SIGNATURES = {
     "mli_engine_get_stats": [_P, ctypes.POINTER(EngineStats)],
     "mli_engine_decoder_result": [_P, _PP, _IP],
     "mli_engine_get_finished": [_P, _I, _IP, _P, _I, _IP],
+    "mli_engine_configure": [_P, _I, _I],
     "mli_engine_set_lean_layers": [_I],
     "mli_engine_set_step_graphs": [_I],
     "mli_engine_last_error": [],

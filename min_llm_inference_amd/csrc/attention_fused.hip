@@ -122,9 +122,9 @@ __global__ __launch_bounds__(WAVES * kWave, MINW) void fused_decode_scan_kernel(
         b = (int)(item % gridDim.x);
         c = (int)(item / gridDim.x);
     }
-    fused_scan_item<E, NJ, NT, TBR, WAVES, DS, SCORES, ScanNoGate, RPI>(q, page_table, lengths, qkt, out, ml, partial, S, D, ct,
-                                                                         ml_per_row, nchunk_max, direct, tail, slots, arrivals,
-                                                                         b, c, c == 0, (int)gridDim.x, smem_raw, ScanNoGate{});
+    fused_scan_item<E, NJ, NT, TBR, WAVES, DS, SCORES, RPI>(q, page_table, lengths, qkt, out, ml, partial, S, D, ct, ml_per_row,
+                                                             nchunk_max, direct, tail, slots, arrivals, b, c, c == 0,
+                                                             (int)gridDim.x, smem_raw);
 }
 
 // grid = (B, kCombineParts).  Every part merges the row's chunk statistics (cheap, identical result), part 0 also
@@ -164,27 +164,27 @@ __global__ __launch_bounds__(kFuThreads) void fused_decode_combine_kernel(
     for (int i = i0 + threadIdx.x; i < i1; i += kFuThreads) qkt_row[i] = i < L ? expf(qkt_row[i] - m) * inv_l : 0.f;
 }
 
-static int g_flash = 1;
-static int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
+static thread_local int g_flash = 1;
+static thread_local int g_flash_variant = 0;  // register-budget variants of the scan kernel (tuning)
 // mli_tune "scan_partial_last": 1 (default) = full chunks first, every row's remainder behind them in pieces of
 // "scan_tail_tokens" tokens; 0 = plain chunk order
-static int g_partial_last = 1;
+static thread_local int g_partial_last = 1;
 void set_partial_last(int v) { g_partial_last = v != 0; }
 // mli_tune "scan_tail_tokens": 0 (default) = the whole remainder as one piece, else a power of two in [64, chunk].
 // Measured at config 4 (bf16, 512-token chunks, lean form): one piece 658.7 us, 256-token pieces 661.9, 128: 668.7,
 // 64: 688.0 -- every item costs about 2.5 us of a workgroup slot (prologue chain lengths -> page pointers -> first K
 // rows, epilogue merge and publication), more than the shorter end of the launch gives back.
-static int g_tail_tokens = 0;
+static thread_local int g_tail_tokens = 0;
 void set_tail_tokens(int v) { g_tail_tokens = v; }
 // mli_tune "scan_dynamic_items": ticketed (row, chunk) assignment.  Off by default: it shortens the kernel by 0.6-1.5 %
 // (4-10 us at config 4), and the hipMemsetAsync that zeroes the counter before every launch costs the stream ~8 us.
-static int g_dynamic_items = 0;
+static thread_local int g_dynamic_items = 0;
 void set_dynamic_items(int v) { g_dynamic_items = v != 0; }
 // mli_tune "scan_merge" (lean mode only): 1 (default) = the workgroup that completes a row merges its chunks inside
 // the scan launch, 0 = the separate combine launch (bit-identical results)
-static int g_row_order = 1;  // mli_tune "scan_row_order": 0 = one-workgroup-per-row grids take the rows in grid order
+static thread_local int g_row_order = 1;  // mli_tune "scan_row_order": 0 = one-workgroup-per-row grids take the rows in grid order
 void set_row_order(int v) { g_row_order = v != 0; }
-static int g_scan_merge = 1;
+static thread_local int g_scan_merge = 1;
 void set_scan_merge(int v) { g_scan_merge = v != 0; }
 void set_flash_decode(int v) { g_flash = v != 0; }
 void set_flash_variant(int v) { g_flash_variant = v; }
@@ -346,36 +346,6 @@ static int launch_fused_decode(const float* q, const void* const* page_table, co
         if (rc) return rc > 0 ? rc + 1 : rc;
     }
     return 1;
-}
-
-// The cut launch_fused_decode<ElemF32> would make for the lean form with the in-kernel merge -- false where that form
-// does not apply (one chunk per row, wide rows, equal page shares, tuning variants): decode_step_fused.hip then leaves the
-// step to the separate launches.  Keep in step with launch_fused_decode.
-bool plan_chunked_scan_f32(int B, int S, int D, size_t ws_bytes, ChunkedScanPlan* p) {
-    using E = ElemF32;
-    if (!g_flash || !g_scan_merge || g_dynamic_items || !g_partial_last || g_flash_variant == 3) return false;
-    if (stream_decode_applies<E>(B, S, D)) return false;
-    const int Du = D / E::EPL;
-    const int nj = ceil_div_i(Du, kWave);
-    if (nj > 2 || D % E::EPL != 0 || S % kPage != 0 || B > kMaxArrivalRows) return false;
-    const int ct = (S <= 128 && B >= 256 && tuned_chunk_tokens() == 0) ? 128 : fused_chunk_tokens(B, S);
-    const int nchunk = ceil_div_i(S, ct);
-    if (nchunk == 1) return false;
-    const size_t stats_bytes = stats_region_bytes_for(B, S);
-    const int ml_per_row = ceil_div_i(S, 64);
-    int tail = g_tail_tokens ? g_tail_tokens : ct;
-    if (tail > ct || tail < 64 || (tail & (tail - 1))) tail = ct;
-    if (nchunk + ct / tail - 1 > ml_per_row) tail = ct;
-    const int slots = nchunk + ct / tail - 1;
-    if ((size_t)B * slots * D * sizeof(float) + stats_bytes > ws_bytes) return false;
-    const size_t red_bytes = (size_t)kFuWaves * nj * kWave * E::EPL * sizeof(float);
-    const size_t stat_bytes_row = (size_t)ml_per_row * 8;
-    p->ct = ct; p->nchunk = nchunk; p->tail = tail; p->slots = slots; p->ml_per_row = ml_per_row;
-    p->grid_rows = nchunk + ct / tail; p->nj = nj;
-    p->smem = (size_t)(ct / kPage) * 8 + (red_bytes > stat_bytes_row ? red_bytes : stat_bytes_row);
-    p->stats_bytes = stats_bytes;
-    p->nt = nt_loads_for(B, S, D, E::kBytes);
-    return true;
 }
 
 // qkt == nullptr selects the lean mode (no scores, in-kernel merge)

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kNvThreads) void naive_decode_scan_kernel(
     __shared__ int last_sh;
 
     const int b = blockIdx.x, c = blockIdx.y;
-    const int L = min(lengths[b], S);
+    const int L = min(max(lengths[b], 0), S);
     const int s0 = c * kNvChunk;
     const int D4 = D >> 2;
     if (L == 0) {  // empty slot: zeros (reference softmax_v: result = 0), written once
@@ -184,12 +184,12 @@ __global__ __launch_bounds__(kNvThreads) void naive_decode_scan_kernel(
     }
     if (direct) return;
     __syncthreads();  // every read of the LDS scratch the merge reuses is done
-    row_publish_merge<kNvThreads, false>(m, l, ml + (int64_t)b * ml_per_row, c, (L + kNvChunk - 1) / kNvChunk, arrivals + b,
-                                         partial + (int64_t)b * nchunk * D, D, out + (int64_t)b * D,
-                                         reinterpret_cast<float*>(red), &last_sh, ScanNoGate{}, b);
+    row_publish_merge<kNvThreads>(m, l, ml + (int64_t)b * ml_per_row, c, (L + kNvChunk - 1) / kNvChunk, arrivals + b,
+                                  partial + (int64_t)b * nchunk * D, D, out + (int64_t)b * D, reinterpret_cast<float*>(red),
+                                  &last_sh);
 }
 
-static int g_naive_fused = 1;  // mli_tune "naive_scan_fused": 0 = the lean contiguous composition is not offered
+static thread_local int g_naive_fused = 1;  // mli_tune "naive_scan_fused": 0 = the lean contiguous composition is not offered
 void set_naive_fused(int v) { g_naive_fused = v != 0; }
 
 static inline bool aligned16_nv(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -201,6 +201,8 @@ int launch_fused_decode_naive(const float* q, const float* kt, const float* v, c
     if (!g_naive_fused || B <= 0 || D % 4 != 0 || S % 4 != 0 || D <= 0 || S <= 0) return 0;
     if (!aligned16_nv(kt) || !aligned16_nv(v) || !aligned16_nv(out)) return 0;
     const int nchunk = ceil_div_i(S, kNvChunk);
+    // the last arriver keeps the row's chunk statistics in the 4 KiB score-partial buffer: 512 (max, sum) pairs
+    if (nchunk > kNvWaves * kWave * 2) return 0;
     const int direct = nchunk == 1;
     const int ml_per_row = ceil_div_i(S, 64);
     float2* ml = nullptr;

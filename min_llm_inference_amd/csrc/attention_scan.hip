@@ -32,7 +32,6 @@ void set_stream_dyn_pct(int v);
 void set_stream_granule(int v);
 void set_dynamic_items(int v);
 void set_partial_last(int v);
-void set_step_fused(int v);
 void set_gemm_split(int v);
 void set_row_order(int v);
 void set_bf16_split(int v);
@@ -43,9 +42,9 @@ void set_fill_compact(int v);
 void set_latest_compact(int v);
 
 // Tuning knobs (mli_tune): 0 = use the built-in heuristic / default.
-static int g_chunk_tokens = 0;
-static int g_nt_loads = 2;  // 0 = default cache policy, 1 = non-temporal, 2 = by working set (nt_loads_for)
-static int g_qkt_token_batch = 8;
+static thread_local int g_chunk_tokens = 0;
+static thread_local int g_nt_loads = 2;  // 0 = default cache policy, 1 = non-temporal, 2 = by working set (nt_loads_for)
+static thread_local int g_qkt_token_batch = 8;
 
 // Sequence chunk (tokens per workgroup) for the split-sequence kernels: the largest power of two in
 // [64, 1024] that still yields >= min_units work units.  With rows as the fast grid dimension the choice is
@@ -612,7 +611,7 @@ int launch_softmax_v_paged(const float* probs, const float* const* page_table, c
 // softmax into softmax.V lengthens every workgroup's prologue (statistics -> exp -> write-back before the first V
 // load), which costs ~10 us at B*S = 4M (BASELINE config 4) but saves a launch and a pass over the scores, worth
 // 10-15 % of the step at B*S = 256K (configs 2/3).
-static int g_fused_softmax = -1;
+static thread_local int g_fused_softmax = -1;
 
 static bool can_fuse(int B, int S, int stats_chunk, void* ws, size_t ws_bytes) {
     const bool want = g_fused_softmax == 1 || (g_fused_softmax < 0 && (int64_t)B * S <= (1 << 20));
@@ -735,8 +734,6 @@ int mli_tune(const char* key, int value) {
         mli::set_row_order(value);
     } else if (k == "gemm_split") {
         mli::set_gemm_split(value);
-    } else if (k == "step_fused") {
-        mli::set_step_fused(value);
     } else if (k == "scan_partial_last") {
         mli::set_partial_last(value);
     } else if (k == "scan_stream") {

@@ -29,8 +29,12 @@ constexpr int kStWaves = kStThreads / kWave;
 constexpr int kStMaxRows = 2048;    // rows whose page counts fit the LDS prefix array
 constexpr int kStMinPages = 16;     // a workgroup's share is never shorter than this many pages (fewer workgroups work then)
 constexpr int kStMinSequence = 1024;
-// Triples per row: static shares are at least 14 pages long (0.88 * kStMinPages), granules at least 16, so a row of W pages
-// yields at most W / 14 + W / 16 + 4 triples -- within the W / 4 slots per row of the workspace from W = 64 (S = 1024) on.
+// Triples per row.  A static share is at least s_min = floor(kStMinPages * (100 - dyn_pct) / 100) pages long (G workgroups
+// share Ps >= P * (1 - dyn_pct / 100) pages and G <= P / kStMinPages), a granule exactly `gran` (the last one apart).  A row
+// of W pages lies in a page interval whose static part meets at most Ls / s_min + 2 shares and whose dynamic part at most
+// Ld / gran + 2 granules, Ls + Ld <= W: at most W / min(s_min, gran) + 4 triples.  The workspace has W / 4 slots per row
+// (one per 64 tokens); stream_triples_bound() is what launch_stream_decode holds against that before every launch (default
+// 4 % / 64 pages: 4 + 4 of 16 at S = 1024; 60 % / 16 pages: 10 + 4).
 
 // -DMLI_SCAN_TRACE: every workgroup records when it passed five points (100 MHz wall clock), read back by
 // mli_debug_stream_trace -- a diagnostic build for tools/stream_trace.py, never the product.
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(kStThreads, 2) void fused_decode_stream_kernel(
 #endif
 }
 
-static int g_scan_stream = 1;   // mli_tune "scan_stream": 1 (default) = lean scans of chip-filling batches take the equal-share form
+static thread_local int g_scan_stream = 1;   // mli_tune "scan_stream": 1 (default) = lean scans of chip-filling batches take the equal-share form
 void set_scan_stream(int v) { g_scan_stream = v != 0; }
 
 // mli_tune "scan_stream_dynamic_pct" / "scan_stream_granule": the share of the page sequence (per cent, 0 = none) that is
@@ -483,18 +487,26 @@ void set_scan_stream(int v) { g_scan_stream = v != 0; }
 // 662.4 | 12 % in 16-page granules 676.9; fp32 1276.9 | 1265.2 | 1233.6 | 1247.7.  The gain of the dynamic part is small
 // because the memory system, not the slowest workgroup, sets the pace: 512 workgroups keep 49 MB in flight, several times
 // what saturates HBM, so the workgroups that are still streaming simply speed up when others finish.
-static int g_stream_dyn_pct = 4;
-static int g_stream_granule = 64;
+static thread_local int g_stream_dyn_pct = 4;
+static thread_local int g_stream_granule = 64;
 void set_stream_dyn_pct(int v) { g_stream_dyn_pct = v < 0 ? 0 : (v > 60 ? 60 : v); }
 void set_stream_granule(int v) { g_stream_granule = v < 16 ? 16 : (v > 256 ? 256 : v); }
-static int g_scan_stream_min = 1 << 21;   // mli_tune "scan_stream_min_tokens": n_batch * n_sequence from which it is used
+static thread_local int g_scan_stream_min = 1 << 21;   // mli_tune "scan_stream_min_tokens": n_batch * n_sequence from which it is used
 void set_scan_stream_min(int v) { g_scan_stream_min = v < 0 ? 0 : v; }
+
+// worst-case number of triples a row can have under the current split (see the header comment)
+static int stream_triples_bound(int W) {
+    const int s_min = std::max(1, kStMinPages * (100 - g_stream_dyn_pct) / 100);
+    const int piece = g_stream_dyn_pct > 0 ? std::min(s_min, g_stream_granule) : s_min;
+    return W / piece + 4;
+}
 
 template <class E>
 bool stream_decode_applies(int B, int S, int D) {
     const int Du = D / E::EPL;
     const int nj = ceil_div_i(Du, kWave);
     if (!g_scan_stream || nj > 2 || D % E::EPL != 0 || S % kPage != 0 || S < kStMinSequence || B > kStMaxRows) return false;
+    if (stream_triples_bound(S / kPage) > ceil_div_i(S, 64)) return false;   // a row's triples would not fit its workspace slots
     // worth it only where the batch fills the chip: below ~2 full rounds of 512-token chunks the chunked grid is as good
     return (int64_t)B * S >= g_scan_stream_min;
 }

@@ -41,9 +41,6 @@ int launch_fill_paged_bf16_embed(const float*, const float*, const int*, uint16_
 // single-launch scan over the contiguous caches (attention_fused_naive.hip): 1 = ran, 0 = shape not covered, else error + (rc > 0)
 int launch_fused_decode_naive(const float*, const float*, const float*, const int*, float*, int, int, int, void*, size_t,
                               hipStream_t);
-// the whole step as one launch (decode_step_fused.hip): 1 = ran, 0 = not a batch for it, else error + (rc > 0)
-int launch_decode_step_fused(float* const*, int*, const float*, const float*, const float*, const float*, const float*,
-                             float*, float*, int*, int, int, int, int, int, int, void*, size_t, void*, size_t, hipStream_t);
 int launch_qkt_paged_bf16(const float*, const uint16_t* const*, const int*, float*, int, int, int, hipStream_t);
 // fp8 (OCP e4m3) pages with bf16 weights: MLI_ELEM_FP8 of the lean entry points
 int launch_latest_paged_fp8(uint8_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*, float*, int, int,
@@ -146,17 +143,6 @@ int mli_paged_decode_step(void* const* page_table, int* lengths, const void* wk,
                           int* decoder_result, int n_batch, int n_sequence, int emb_dim, int n_vocab,
                           int n_decoder_results, int i_decoder, int elem_bf16, void* workspace, size_t workspace_bytes,
                           void* decoder_scratch, size_t decoder_scratch_bytes, void* stream) {
-    if (elem_bf16 == MLI_ELEM_F32 && n_decoder_results > 0 && i_decoder >= 0 && i_decoder < n_decoder_results) {
-        // small batches: projection, scan, logits + argmax and the token pick as roles of ONE launch
-        const mli::WsBody body = mli::ws_body(workspace, workspace_bytes);
-        const int fused = mli::launch_decode_step_fused(
-            reinterpret_cast<float* const*>(page_table), lengths, static_cast<const float*>(wk),
-            static_cast<const float*>(wq), static_cast<const float*>(wv), emb_table, wpe_table, q_output, attention_result,
-            decoder_result, n_batch, n_sequence, emb_dim, n_vocab, n_decoder_results, i_decoder, body.ptr, body.bytes,
-            decoder_scratch, decoder_scratch_bytes, mli::as_stream(stream));
-        if (fused == 1) return 0;
-        if (fused != 0) return fused < 0 ? fused : fused - 1;
-    }
     const int rc = mli_paged_attention_lean(page_table, lengths, wk, wq, wv, /*new_batch_idx=*/nullptr, q_output,
                                             attention_result, n_batch, n_sequence, emb_dim, /*n_new_items=*/0, elem_bf16,
                                             workspace, workspace_bytes, stream);

@@ -1,6 +1,4 @@
-// The panel GEMM's workgroup body (see proj_gemm_panel.hip for what the kernel is and why): a device function, so that
-// the same tile code runs as its own launch (gemm_f32_panel_kernel) and as a role inside the one-launch decode step
-// (decode_step_fused.hip), where its outputs are handed to other workgroups of the SAME launch.
+// The panel GEMM's workgroup body (see proj_gemm_panel.hip for what the kernel is and why).
 #pragma once
 
 #include "gemm_common.hpp"
@@ -14,23 +12,10 @@ constexpr int kPanelThreads = 256;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-struct PanelNoGate {
-    __device__ __forceinline__ void operator()() const {}
-};
-
-// write-through (sc1) stores for results another workgroup of the same launch reads back (MI355X_MICROARCH.md,
-// inter-workgroup visibility: the consumer still runs an agent acquire before its loads)
-__device__ __forceinline__ void panel_store_wt(float* p, float v) {
-    typedef float __attribute__((address_space(1)))* gf32_ptr;
-    __hip_atomic_store((gf32_ptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // B operand source: BT = false: w[k][n] (projection weights), BT = true: w[n][k] (embedding table, logits)
-// bx, by: the tile's grid position (gemm_f32_panel_kernel: blockIdx.x, blockIdx.y).  WT: results are stored
-// write-through.  `gate()` is called once by every thread after the B panel has been requested and before the first A
-// row is read: the fused step waits there for the rows' producers.
-template <int MODE, bool BT, bool WT, class Gate>
-__device__ __forceinline__ void gemm_panel_tile(const GemmArgs& g, int bx, int by, unsigned char* panel_smem, Gate gate) {
+// bx, by: the tile's grid position (gemm_f32_panel_kernel: blockIdx.x, blockIdx.y).
+template <int MODE, bool BT>
+__device__ __forceinline__ void gemm_panel_tile(const GemmArgs& g, int bx, int by, unsigned char* panel_smem) {
     float* As = reinterpret_cast<float*>(panel_smem);   // [PM][LDK]
     float* Bs = As + PM * LDK;                           // [PN][LDK]
     const float** a_ptr = reinterpret_cast<const float**>(Bs + PN * LDK);  // [PM]
@@ -75,7 +60,6 @@ __device__ __forceinline__ void gemm_panel_tile(const GemmArgs& g, int bx, int b
         a_ptr[tid] = r.a;
         o_ptr[tid] = r.o;
     }
-    gate();
     __syncthreads();
     const float* a_src[8];
 #pragma unroll
@@ -163,13 +147,7 @@ __device__ __forceinline__ void gemm_panel_tile(const GemmArgs& g, int bx, int b
             int ix = best_i[tid * 2];
             argmax_take(v, ix, best_v[tid * 2 + 1], best_i[tid * 2 + 1]);
             RowBest* dst = g.row_best + (int64_t)(m0 + tid) * tiles_n + tile;
-            if (WT) {
-                typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
-                const unsigned long long packed = ((unsigned long long)(unsigned)ix << 32) | __float_as_uint(v);
-                __hip_atomic_store((gu64_ptr)dst, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                *dst = RowBest{v, ix};
-            }
+            *dst = RowBest{v, ix};
         }
         return;
     }
@@ -180,8 +158,7 @@ __device__ __forceinline__ void gemm_panel_tile(const GemmArgs& g, int bx, int b
     for (int r = 0; r < 4; ++r) {
         float* op = o_ptr[wm + 4 * fk + r];
         if (op != nullptr && n < g.N) {
-            if (WT) panel_store_wt(op + (int64_t)n * o_stride, acc[r]);
-            else op[(int64_t)n * o_stride] = acc[r];
+            op[(int64_t)n * o_stride] = acc[r];
         }
     }
 }

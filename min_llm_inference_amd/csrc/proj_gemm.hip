@@ -405,7 +405,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kGemmThreads : kGemmThreads) void gemm_
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static int g_fill_compact = 1;  // mli_tune "fill_compact": 0 = one tile grid per new row (the reference's decomposition)
+static thread_local int g_fill_compact = 1;  // mli_tune "fill_compact": 0 = one tile grid per new row (the reference's decomposition)
 void set_fill_compact(int v) { g_fill_compact = v != 0; }
 int fill_compact(int n_new) { return g_fill_compact && n_new <= kMaxCompactRows ? 1 : 0; }
 // mli_tune "latest_compact": 0 = the decode projection multiplies empty rows as zeros, 1 (default) = it multiplies a
@@ -413,19 +413,19 @@ int fill_compact(int n_new) { return g_fill_compact && n_new <= kMaxCompactRows 
 // list (a prefix sum over the batch rows): ~1.8 us of prologue -- config 4's projection (emb_dim 512) takes 9.4 us without
 // it and 11.2 with it, and could save 3-4 us at best from a batch that is 40 % empty slots; at emb_dim 2048 (222 us) the same
 // batch saves 90 us.  So: only for reductions of 1024 and more.
-static int g_latest_compact = 1;
+static thread_local int g_latest_compact = 1;
 void set_latest_compact(int v) { g_latest_compact = v < 0 ? 0 : (v > 2 ? 2 : v); }
 int latest_compact(int n_batch, int k_dim) {
     if (g_latest_compact == 0 || n_batch > kMaxCompactRows) return 0;
     return g_latest_compact == 2 || k_dim >= 1024 ? 1 : 0;
 }
 
-static int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
+static thread_local int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
 void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
 int deep_k_tiles_enabled() { return g_deep_k_tiles; }
-static int g_gemm_split = 1;  // mli_tune "gemm_split": 0 = never the loader / MFMA wave split of the 64-row-tile kernel
+static thread_local int g_gemm_split = 1;  // mli_tune "gemm_split": 0 = never the loader / MFMA wave split of the 64-row-tile kernel
 void set_gemm_split(int v) { g_gemm_split = v != 0; }
-static int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
+static thread_local int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
 void set_gemm_tall_tiles(int v) { g_gemm_tall_tiles = v < 0 ? 0 : (v > 2 ? 2 : v); }
 bool gemm_use_tall_tiles(int64_t tall_workgroups) { return g_gemm_tall_tiles == 2 || (g_gemm_tall_tiles == 1 && tall_workgroups >= 512); }
 
@@ -544,7 +544,7 @@ int launch_fill_paged(float* const* page_table, const int* new_idx, const int* l
 
 // bf16 tile engine: 1 = native v_mfma_f32_32x32x16_bf16 (proj_gemm_bf16.hip, default), 0 = operands widened to
 // fp32 in LDS + fp32 MFMA (bit-identical to a sequential fp32 sum; kept for parity checks).  mli_tune knob.
-static int g_bf16_native_mfma = 1;
+static thread_local int g_bf16_native_mfma = 1;
 void set_bf16_native_mfma(int v) { g_bf16_native_mfma = v != 0; }
 int launch_latest_paged_bf16_native(uint16_t* const*, const int*, const uint16_t*, const uint16_t*, const uint16_t*,
                                     float*, int, int, int, hipStream_t);

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs
     }
 }
 
-static int g_bf16_split = 1;  // mli_tune "gemm_bf16_split": 0 = the 128 x 64 tiled kernel for the large decode projection too
+static thread_local int g_bf16_split = 1;  // mli_tune "gemm_bf16_split": 0 = the 128 x 64 tiled kernel for the large decode projection too
 void set_bf16_split(int v) { g_bf16_split = v != 0; }
 
 int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,

@@ -23,10 +23,10 @@ namespace mli {
 template <int MODE, bool BT>
 __global__ __launch_bounds__(kPanelThreads) void gemm_f32_panel_kernel(GemmArgs g) {
     extern __shared__ __align__(16) unsigned char panel_smem[];
-    gemm_panel_tile<MODE, BT, false>(g, blockIdx.x, blockIdx.y, panel_smem, PanelNoGate{});
+    gemm_panel_tile<MODE, BT>(g, blockIdx.x, blockIdx.y, panel_smem);
 }
 
-static int g_gemm_panel = 1;  // mli_tune "gemm_panel": 0 = never, 1 = for small grids (default), 2 = whenever the shape allows
+static thread_local int g_gemm_panel = 1;  // mli_tune "gemm_panel": 0 = never, 1 = for small grids (default), 2 = whenever the shape allows
 void set_gemm_panel(int v) { g_gemm_panel = v < 0 ? 0 : (v > 2 ? 2 : v); }
 
 // The shapes this kernel is for: float4-aligned operands, and so few 64x64 tiles that the tiled kernel would leave most

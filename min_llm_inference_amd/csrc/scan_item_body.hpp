@@ -1,6 +1,5 @@
 // The single-pass scan's workgroup body (what it is and why: attention_fused.hip): one (row, chunk) item of the chunked
-// grid, as a device function -- it runs as its own launch (fused_decode_scan_kernel) and as a role inside the one-launch
-// decode step (decode_step_fused.hip), where a Gate object connects it to the other roles.
+// grid (fused_decode_scan_kernel), and the publish / merge tail it shares with the contiguous scan (attention_fused_naive.hip).
 #pragma once
 
 #include <type_traits>
@@ -21,14 +20,6 @@ __device__ unsigned long long mli_scan_trace[kTraceSlots * 8];
 
 constexpr int kFuThreads = 256;
 constexpr int kFuWaves = kFuThreads / kWave;
-
-// How the chunked grid cuts a batch (lean form, in-kernel merge): filled in by plan_chunked_scan_f32 (attention_fused.hip)
-// with the same rules launch_fused_decode applies, for the launchers that run the item body as a role of a larger kernel.
-struct ChunkedScanPlan {
-    int ct, nchunk, tail, slots, ml_per_row, grid_rows, nj;
-    size_t smem, stats_bytes;
-    bool nt;
-};
 
 // number of (m, l, partial) triples a row of length L produces: full chunks + pieces of the remainder
 __host__ __device__ __forceinline__ int row_items(int L, int ct, int tail) {
@@ -54,30 +45,16 @@ __host__ __device__ __forceinline__ int row_items(int L, int ct, int tail) {
 //      same order as fused_decode_combine_kernel, so the result is bit-identical to the two-launch form -- and puts
 //      the counter back to zero for the next launch.  (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload +
 //      every storing wave's vmcnt(0) + barrier + counter add; consumer: agent acquire + vmcnt(0) + barrier, then loads.)
-__device__ __forceinline__ void scan_store_wt(float* p, float v) {  // write-through (sc1) store
-    typedef float __attribute__((address_space(1)))* gf32_ptr;
-    __hip_atomic_store((gf32_ptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The gate of the stand-alone launch: nothing to wait for, nobody to tell.
-struct ScanNoGate {
-    static constexpr bool kGated = false;
-    __device__ __forceinline__ void length_read(int) const {}
-    __device__ __forceinline__ void wait_inputs(int) const {}
-    __device__ __forceinline__ void row_done(int) const {}
-    __device__ __forceinline__ void before_prefetch() const {}
-};
-
 // The tail of every item of a row that has several: the item's partial output row has been stored write-through (sc1)
 // at partial_row[c]; here its (m, l) pair follows, the arrival is counted, and the workgroup whose arrival completes the
 // row merges the row's nc triples in item order into out_row (MI355X_MICROARCH.md, inter-workgroup visibility: sc1
 // payload + every storing wave's vmcnt(0) + barrier + counter add; the last arriver: agent acquire + vmcnt(0) + barrier,
 // then loads) and puts the counter back to zero.  All THREADS threads call it.  lds: >= nc float2 of scratch no thread
 // still reads; last_sh: one LDS int.
-template <int THREADS, bool GATED, class Gate>
+template <int THREADS>
 __device__ __forceinline__ void row_publish_merge(float m, float l, float2* ml_row, int c, int nc, unsigned* arrival,
                                                   const float* partial_row, int D, float* out_row, float* lds,
-                                                  int* last_sh, Gate gate, int b) {
+                                                  int* last_sh) {
     typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
     typedef unsigned __attribute__((address_space(1)))* gu32_ptr;
     if (threadIdx.x == 0) {
@@ -134,41 +111,22 @@ __device__ __forceinline__ void row_publish_merge(float m, float l, float2* ml_r
                 }
             }
         }
-        if constexpr (GATED) {
-            const __amdgpu_buffer_rsrc_t orow2 = __builtin_amdgcn_make_buffer_rsrc(out_row, 0, D * (int)sizeof(float), 0x00020000);
-            fu_u32x4 raw;
-            raw.x = __float_as_uint(r[0] * inv_l); raw.y = __float_as_uint(r[1] * inv_l);
-            raw.z = __float_as_uint(r[2] * inv_l); raw.w = __float_as_uint(r[3] * inv_l);
-            __builtin_amdgcn_raw_buffer_store_b128(raw, orow2, d * (int)sizeof(float), 0, 16);  // sc1: write-through
-        } else {
-            *reinterpret_cast<float4*>(out_row + d) = make_float4(r[0] * inv_l, r[1] * inv_l, r[2] * inv_l, r[3] * inv_l);
-        }
-    }
-    if constexpr (GATED) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, then the barrier, then the count
-        __syncthreads();
-        if (threadIdx.x == 0) gate.row_done(b);
+        *reinterpret_cast<float4*>(out_row + d) = make_float4(r[0] * inv_l, r[1] * inv_l, r[2] * inv_l, r[3] * inv_l);
     }
 }
 
 // b, c: the item (row, grid row); first_grid_row: this workgroup is the one that writes the zero result of an empty row.
-// Gate (kGated): the row's q and newest K / V rows come from another workgroup of the SAME launch --
-//   gate.length_read(b)   after lengths[b] has been read (every path, before any return);
-//   gate.wait_inputs(b)   all threads; returns once the row's projection is visible (agent acquire done, barrier passed);
-//                         K / V rows of OLDER pages are requested before it, q and the row's last page after it;
-//   gate.row_done(b)      thread 0 of the workgroup that wrote attention_result[b] (write-through, drained, barrier passed).
 // RPI = token slots per load instruction (scan_common.hpp; 1 except for narrow fp8 rows): a batch is TBR instructions =
 //   TBR * RPI slots
-template <class E, int NJ, bool NT, int TBR, int WAVES, bool DS, bool SCORES, class Gate, int RPI = 1>
+template <class E, int NJ, bool NT, int TBR, int WAVES, bool DS, bool SCORES, int RPI = 1>
 __device__ __forceinline__ void fused_scan_item(
     const float* __restrict__ q, const void* const* __restrict__ page_table, const int* __restrict__ lengths,
     float* __restrict__ qkt, float* __restrict__ out, float2* ml, float* partial,
     int S, int D, int ct, int ml_per_row, int nchunk_max, int direct, int tail,
-    int slots, unsigned* arrivals, int b, int c, bool first_grid_row, int trace_stride, unsigned char* smem_raw, Gate gate) {
+    int slots, unsigned* arrivals, int b, int c, bool first_grid_row, int trace_stride, unsigned char* smem_raw) {
     constexpr int EPL = E::EPL;
-    constexpr bool GATED = Gate::kGated;
     constexpr int LPR = kWave / RPI;   // lanes per token row
-    static_assert(RPI == 1 || (NJ == 1 && !DS && !GATED), "several rows per instruction: rows of one lane load, whole pages per wave");
+    static_assert(RPI == 1 || (NJ == 1 && !DS), "several rows per instruction: rows of one lane load, whole pages per wave");
     const void** ptr_sh = reinterpret_cast<const void**>(smem_raw);                       // ct/16 page pointers
     float* red = reinterpret_cast<float*>(smem_raw + (size_t)(ct / kPage) * 8);            // [waves][NJ*64*EPL]
     __shared__ float2 wave_ml[WAVES];
@@ -206,29 +164,14 @@ __device__ __forceinline__ void fused_scan_item(
         // lanes beyond the row get an offset outside the page block: the buffer range check returns zeros for
         // them, so the loads need no per-lane predication
         voff[j] = live[j] ? (unsigned)u * 16u + (unsigned)lane_grp * (unsigned)(3 * D * E::kBytes) : 0x40000000u;
-        if constexpr (!GATED) {
 #pragma unroll
-            for (int e = 0; e < EPLc; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPLc + e] : 0.f;
-        }
+        for (int e = 0; e < EPLc; ++e) qr[j][e] = live[j] ? q[(int64_t)b * D + u * EPLc + e] : 0.f;
     }
     const int L = min(lengths[b], S);
-    if constexpr (GATED) {
-        // the length is in a register from here on: whoever rewrites lengths[b] later in this launch waits for this
-        asm volatile("" ::"v"(L) : "memory");
-        if (threadIdx.x == 0) gate.length_read(b);
-    }
     if (arrivals != nullptr && L == 0) {
         // in-kernel merge: no workgroup arrives for an empty row, so its zero result is written here, once
         if (first_grid_row) {
-            for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) {
-                if (GATED) scan_store_wt(out + (int64_t)b * D + i, 0.f);
-                else out[(int64_t)b * D + i] = 0.f;
-            }
-            if constexpr (GATED) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) gate.row_done(b);
-            }
+            for (int i = threadIdx.x; i < D; i += (WAVES * kWave)) out[(int64_t)b * D + i] = 0.f;
         }
         return;
     }
@@ -315,38 +258,10 @@ __device__ __forceinline__ void fused_scan_item(
     constexpr int PSTEP = DS ? 1 : WAVES;
     const int p_first = DS ? 0 : wave;
     const char* page = p_first < npages ? page_ptr(p_first) : nullptr;
-    // GATED: the projection of this row may still be running.  What it writes of the pages is the K and V row of token
-    // L - 1, so pages other than the row's last one are requested at once (wave 0 polls the projection's counter and
-    // would get its answer behind its own page loads: it waits first), q and the last page after the gate.
-    bool requested = false;
-    if constexpr (GATED) gate.before_prefetch();
-    if (p_first < npages && (!GATED || (wave != 0 && s0 / kPage + p_first != (L - 1) / kPage))) {
-        // (not "page != nullptr": a null table entry is a page too -- it reads as zeros)
+    if (p_first < npages) {   // (not "page != nullptr": a null table entry is a page too -- it reads as zeros)
         issue(std::integral_constant<int, 0>{}, page);
         issue(std::integral_constant<int, 1>{}, page);
         issue(std::integral_constant<int, 2>{}, page);
-        requested = true;
-    }
-    if constexpr (GATED) {
-        gate.wait_inputs(b);
-        // q is a __restrict__ parameter: without this the compiler may treat the row as unwritten during the kernel and
-        // move its loads above the wait
-        const float* q_now = q;
-        asm volatile("" : "+s"(q_now)::"memory");
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int u = (DS ? wave * NJ * kWave : 0) + lane + j * kWave;
-#pragma unroll
-            for (int e = 0; e < EPLc; ++e)  // sc1 loads: never served from this CU's L1
-                qr[j][e] = live[j] ? __hip_atomic_load((gf_ptr)(q_now + (int64_t)b * D + u * EPLc + e), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0.f;
-        }
-        if (p_first < npages && !requested) {
-            issue(std::integral_constant<int, 0>{}, page);
-            issue(std::integral_constant<int, 1>{}, page);
-            issue(std::integral_constant<int, 2>{}, page);
-        }
     }
     for (int pi = p_first; pi < npages; pi += PSTEP) {
         const bool has_next = pi + PSTEP < npages;
@@ -510,9 +425,9 @@ __device__ __forceinline__ void fused_scan_item(
         if (threadIdx.x == 0) ml[(int64_t)b * ml_per_row + c] = make_float2(m, l);
     } else {
         // ---- publish the triple, count the arrival; the workgroup that completes the row merges it ----
-        row_publish_merge<WAVES * kWave, GATED>(m, l, ml + (int64_t)b * ml_per_row, c, row_items(L, ct, tail), arrivals + b,
-                                                partial + (int64_t)b * slots * D, D, out + (int64_t)b * D, red,
-                                                reinterpret_cast<int*>(wave_ml), gate, b);
+        row_publish_merge<WAVES * kWave>(m, l, ml + (int64_t)b * ml_per_row, c, row_items(L, ct, tail), arrivals + b,
+                                         partial + (int64_t)b * slots * D, D, out + (int64_t)b * D, red,
+                                         reinterpret_cast<int*>(wave_ml));
     }
     MLI_TRACE(4);
 #ifdef MLI_SCAN_TRACE

@@ -36,6 +36,11 @@ class Engine:
     def use_private_stream(self):
         self._check(self._lib.mli_engine_use_private_stream(self._h))
 
+    def configure(self, lean_layers=None, step_graphs=None):
+        """This engine's own composition / replay switches (mli_engine_configure); None leaves a value as it is."""
+        self._check(self._lib.mli_engine_configure(self._h, -1 if lean_layers is None else int(lean_layers),
+                                                   -1 if step_graphs is None else int(step_graphs)))
+
     def set_pipelined(self, enabled=True):
         self._check(self._lib.mli_engine_set_pipelined(self._h, int(enabled)))
 

@@ -14,6 +14,13 @@ enum class Mode { Sync, Async };
 
 struct Block;  // opaque; owns one allocation (+ the readiness event of the async flavour)
 
+// The flavour a Tensor gets when its constructor is not told one.  The reference fixes it per BUILD
+// (-DUSE_ASYNC_ALLOC -> DEFAULT_ALLOC_METHOD, include/tensor.hpp:21-25) and runs its whole test suite under both
+// (Makefile:20-30); here the library is built once, so the flavour a host compiled with -DDEFAULT_ALLOC_METHOD=1 asks for is
+// registered at load time (tensor.hpp) and every tensor of the process -- the library's own scratch included -- follows it.
+void set_process_default_mode(Mode mode);
+Mode process_default_mode();
+
 Block* acquire(std::size_t bytes, Space space, Mode mode);
 void release(Block* block) noexcept;
 void* pointer(Block* block);                       // async blocks wait for their last copy first

@@ -26,21 +26,25 @@ struct Scratch {
 Scratch attention_scratch(int n_batch, int n_sequence, int emb_dim);
 void release_attention_scratch(void* stream) noexcept;  // frees the buffers tied to a stream that is going away
 
-// What the layers run (process-wide; default true): the LEAN compositions -- attention without materialising scores /
+// The three switches below are PER THREAD, like the device and the compute stream: they apply to what the calling thread
+// runs afterwards (an engine is driven by one thread at a time; engines created through the C ABI carry their own values,
+// mli_engine.h).
+//
+// What the layers run (default true): the LEAN compositions -- attention without materialising scores /
 // probabilities in the layer's qkt_output scratch, decoder head with the argmax as the logits GEMM's epilogue instead of
 // materialising emb_score.  Outputs a caller of forward() can observe (attention_result, tokens, lengths, pages) are
 // bit-identical either way; false reproduces the reference's launch sequence, scratch contents included.
 void set_lean_layers(bool enabled);
 bool lean_layers();
 
-// Which loop start_paged_attention_*_inference_engine runs (process-wide; default false): the pipelined loop
+// Which loop start_paged_attention_*_inference_engine runs (default false): the pipelined loop
 // (pipelined_engine.h: the host one step behind the GPU, same tokens per item) wherever it applies -- up to
 // PAGE_BLOCK_SIZE / 2 forward rounds, no length-reset quirk --, or, with true, always the reference's sequential order
 // forward -> process_decoder_result -> allocate_or_free_memory_blocks_if_needed -> insert_new_items.
 void set_sequential_engine_loop(bool enabled);
 bool sequential_engine_loop();
 
-// hipGraph replay of decode forwards (step_graph.h); process-wide, default false.
+// hipGraph replay of decode forwards (step_graph.h); default false.
 void set_step_graphs(bool enabled);
 bool step_graphs();
 

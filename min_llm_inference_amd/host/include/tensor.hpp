@@ -16,11 +16,29 @@ enum class DeviceType { HOST, DEVICE };
 
 enum class TensorDataType { SYNC_ALLOCATE = 0, ASYNC_ALLOCATE = 1 };
 
-#ifndef DEFAULT_ALLOC_METHOD
+#ifdef DEFAULT_ALLOC_METHOD
+#define MLI_ALLOC_METHOD_GIVEN 1
+#else
 #define DEFAULT_ALLOC_METHOD 0
 #endif
 
 constexpr TensorDataType DEFAULT_TENSOR_DATA_TYPE = static_cast<TensorDataType>(DEFAULT_ALLOC_METHOD);
+
+#ifdef MLI_ALLOC_METHOD_GIVEN
+// A host built with -DDEFAULT_ALLOC_METHOD=<n> (the reference's USE_ASYNC_ALLOC builds) makes <n> the flavour of every
+// tensor in the process, the library's own included (memory.h: set_process_default_mode): registered before any tensor of
+// this translation unit can be constructed.
+namespace {
+const bool mli_default_alloc_method_registered =
+    (mli::mem::set_process_default_mode(DEFAULT_ALLOC_METHOD != 0 ? mli::mem::Mode::Async : mli::mem::Mode::Sync), true);
+}
+#endif
+
+// the flavour of a tensor whose constructor is not told one
+inline TensorDataType default_tensor_data_type() {
+    return mli::mem::process_default_mode() == mli::mem::Mode::Async ? TensorDataType::ASYNC_ALLOCATE
+                                                                     : TensorDataType::SYNC_ALLOCATE;
+}
 
 // Storage of one tensor.  The reference splits this into SyncTensorData / AsyncTensorData; here the
 // flavour is a property of the backend block.
@@ -89,7 +107,7 @@ template <typename T>
 class Tensor {
 public:
     Tensor(const std::vector<std::size_t>& shape, DeviceType device = DeviceType::HOST,
-           TensorDataType tensor_data_type = DEFAULT_TENSOR_DATA_TYPE)
+           TensorDataType tensor_data_type = default_tensor_data_type())
         : shape_(shape), size_(1), device_(device) {
         for (std::size_t d : shape_) size_ *= d;
         data_ = std::make_shared<TensorData<T>>(size_, device, tensor_data_type);

@@ -1,5 +1,6 @@
 // extern "C" engine sessions (include/mli_engine.h): the reference's engine loops in resumable form, so a
 // host in another language -- or bench.py -- can step them and interleave the multi-GPU token gather.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,10 @@
 namespace {
 
 thread_local std::string g_last_error;
+// what an engine created from now on starts with (mli_engine_set_lean_layers / mli_engine_set_step_graphs); every engine
+// keeps its own copy, installed for the calling thread while one of its entry points runs
+std::atomic<bool> g_default_lean_layers{true};
+std::atomic<bool> g_default_step_graphs{false};
 
 TensorFloat upload(const float* host, std::vector<size_t> shape) {
     TensorFloat staging(shape, DeviceType::HOST);
@@ -63,6 +68,8 @@ struct mli_engine {
     }
     bool use_pipelined() const { return pipelined == 1 || (pipelined == -1 && pipelined_applies()); }
     void* stream = nullptr;     // private compute stream (mli_engine_use_private_stream), else the thread's
+    bool lean_layers = g_default_lean_layers.load();   // this engine's composition and replay switches (runtime.h)
+    bool step_graphs = g_default_step_graphs.load();
 
     ~mli_engine() {
         if (stream) {
@@ -74,13 +81,21 @@ struct mli_engine {
     // every entry point runs under this: device, stream and counter of THIS engine for the calling thread
     struct Scope {
         void* saved;
-        explicit Scope(mli_engine* e) : saved(mli::runtime::compute_stream()) {
+        bool saved_lean, saved_graphs, saved_sequential;
+        explicit Scope(mli_engine* e)
+            : saved(mli::runtime::compute_stream()), saved_lean(mli::runtime::lean_layers()),
+              saved_graphs(mli::runtime::step_graphs()), saved_sequential(mli::runtime::sequential_engine_loop()) {
             mli::runtime::use_device(e->cfg.device);
             if (e->stream) mli::runtime::set_compute_stream(e->stream);
+            mli::runtime::set_lean_layers(e->lean_layers);
+            mli::runtime::set_step_graphs(e->step_graphs);
             set_thread_throughput_counter(&e->counter);
         }
         ~Scope() {
             mli::runtime::set_compute_stream(saved);
+            mli::runtime::set_lean_layers(saved_lean);
+            mli::runtime::set_step_graphs(saved_graphs);
+            mli::runtime::set_sequential_engine_loop(saved_sequential);
             set_thread_throughput_counter(nullptr);
         }
     };
@@ -262,9 +277,19 @@ struct mli_engine {
 
 extern "C" {
 
-void mli_engine_set_lean_layers(int enabled) { mli::runtime::set_lean_layers(enabled != 0); }
+void mli_engine_set_lean_layers(int enabled) { g_default_lean_layers.store(enabled != 0); }
 
-void mli_engine_set_step_graphs(int enabled) { mli::runtime::set_step_graphs(enabled != 0); }
+void mli_engine_set_step_graphs(int enabled) { g_default_step_graphs.store(enabled != 0); }
+
+int mli_engine_configure(mli_engine* e, int lean_layers, int step_graphs) {
+    MLI_GUARD({
+        if (e->started) throw std::runtime_error("mli_engine_configure after the engine has started");
+        if (lean_layers >= 0) e->lean_layers = lean_layers != 0;
+        if (step_graphs >= 0) e->step_graphs = step_graphs != 0;
+        if (e->cfg.kind == MLI_ENGINE_PAGED_FP8 && !e->lean_layers)
+            throw std::runtime_error("the fp8 engine has the lean compositions only");
+    })
+}
 
 const char* mli_engine_last_error(void) { return g_last_error.c_str(); }
 

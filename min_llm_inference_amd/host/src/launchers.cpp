@@ -46,10 +46,13 @@ mli::runtime::Scratch mli::runtime::attention_scratch(int n_batch, int n_sequenc
     return {slot->data(), need};
 }
 
+// Per THREAD, like the device and the compute stream (an engine is driven by one thread at a time, and the engine C ABI
+// installs each engine's own values for the duration of a call: engine_api.cpp, mli_engine::Scope): two engines in one
+// process cannot change each other's composition.
 namespace {
-bool g_lean_layers = true;
-bool g_sequential_engine_loop = false;
-bool g_step_graphs = false;
+thread_local bool g_lean_layers = true;
+thread_local bool g_sequential_engine_loop = false;
+thread_local bool g_step_graphs = false;
 }
 void mli::runtime::set_step_graphs(bool enabled) { g_step_graphs = enabled; }
 bool mli::runtime::step_graphs() { return g_step_graphs; }

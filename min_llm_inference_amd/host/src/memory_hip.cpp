@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
 
+#include <atomic>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -67,6 +68,12 @@ void range_pop() { roctxRangePop(); }
 }  // namespace runtime
 
 namespace mem {
+
+namespace {
+std::atomic<int> g_default_mode{static_cast<int>(Mode::Sync)};
+}
+void set_process_default_mode(Mode mode) { g_default_mode.store(static_cast<int>(mode)); }
+Mode process_default_mode() { return static_cast<Mode>(g_default_mode.load()); }
 
 struct Block {
     void* ptr = nullptr;
@@ -181,7 +188,12 @@ void copy(Block* dst, const Block* src, std::size_t byte_offset, std::size_t byt
         // the copy must not start before the kernels queued so far have run (a D2H of their results, or an H2D into
         // a buffer they still read), so the transfer stream first waits for that point of the compute stream.
         if (hipStream_t cs = static_cast<hipStream_t>(runtime::compute_stream())) {
-            thread_local hipEvent_t ordered = nullptr;
+            // one event per (thread, device): an event belongs to the device that was current when it was created, and a
+            // thread may drive engines on several devices (row-sharded replicas in one process)
+            constexpr int kMaxOrderedDevices = 64;
+            thread_local hipEvent_t ordered_of[kMaxOrderedDevices] = {};
+            if (dst->device < 0 || dst->device >= kMaxOrderedDevices) throw std::runtime_error("device ordinal out of range");
+            hipEvent_t& ordered = ordered_of[dst->device];
             if (ordered == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ordered, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(ordered, cs));
             HIP_CHECK(hipStreamWaitEvent(ts, ordered, 0));

@@ -37,14 +37,18 @@ long long run_paged_engine_pipelined(ItemStorage& item_storage, ProcessingStorag
     if (pages.length_reset_quirk())
         throw std::runtime_error("the pipelined engine does not reproduce the reference's length-reset quirk");
     const int B = static_cast<int>(n_batch_size), S = static_cast<int>(n_sequence);
-    TensorInt inp_device({n_batch_size, n_sequence}, DeviceType::DEVICE), inp_host({n_batch_size, n_sequence}, DeviceType::HOST);
-    TensorInt lengths_device({n_batch_size}, DeviceType::DEVICE), lengths_host({n_batch_size}, DeviceType::HOST);
-    TensorInt new_idx_device({n_batch_size}, DeviceType::DEVICE);
+    // The loop's own buffers are sync-flavour whatever the process default (memory.h): its per-slot updates are the
+    // stream-ordered, non-blocking copies of copy_async, which the async flavour -- every copy on the transfer stream,
+    // every data() a wait -- does not offer.
+    constexpr TensorDataType kSync = TensorDataType::SYNC_ALLOCATE;
+    TensorInt inp_device({n_batch_size, n_sequence}, DeviceType::DEVICE, kSync), inp_host({n_batch_size, n_sequence}, DeviceType::HOST, kSync);
+    TensorInt lengths_device({n_batch_size}, DeviceType::DEVICE, kSync), lengths_host({n_batch_size}, DeviceType::HOST, kSync);
+    TensorInt new_idx_device({n_batch_size}, DeviceType::DEVICE, kSync);
     // staging for the new-row indices of forward(k) is reused for forward(k+2): by then the marker of step k+1,
     // recorded after forward(k+1) was queued, has been waited for, so the copy that fed forward(k) has executed
-    TensorInt new_idx_host[2] = {TensorInt({n_batch_size}, DeviceType::HOST), TensorInt({n_batch_size}, DeviceType::HOST)};
+    TensorInt new_idx_host[2] = {TensorInt({n_batch_size}, DeviceType::HOST, kSync), TensorInt({n_batch_size}, DeviceType::HOST, kSync)};
     const size_t n_rounds = static_cast<size_t>(R);
-    TensorInt result_device({n_batch_size, n_rounds}, DeviceType::DEVICE), result_host({n_batch_size, n_rounds}, DeviceType::HOST);
+    TensorInt result_device({n_batch_size, n_rounds}, DeviceType::DEVICE, kSync), result_host({n_batch_size, n_rounds}, DeviceType::HOST, kSync);
     MarkerHandle marker;
 
     // first_step[b] = index of the first forward this occupant of slot b takes part in; -1 = slot empty

@@ -207,6 +207,18 @@ int main() {
             ++mismatched;
     std::printf("items whose tokens differ between engines: %d\n", mismatched);
     failures += mismatched != 0;
+    // one number over every item's tokens: the two allocation flavours (this file built with and without
+    // -DDEFAULT_ALLOC_METHOD=1, as the reference's Makefile:20-30 runs its suite) must print the same
+    unsigned long long checksum = 1469598103934665603ull;
+    for (const auto& kv : naive) {
+        checksum = (checksum ^ (unsigned long long)kv.first) * 1099511628211ull;
+        for (int t : kv.second) checksum = (checksum ^ (unsigned long long)(unsigned)t) * 1099511628211ull;
+    }
+    std::printf("allocation flavour: %s (DEFAULT_ALLOC_METHOD=%d); process default seen by the library: %s\n",
+                DEFAULT_ALLOC_METHOD ? "ASYNC_ALLOCATE" : "SYNC_ALLOCATE", DEFAULT_ALLOC_METHOD,
+                mli::mem::process_default_mode() == mli::mem::Mode::Async ? "async" : "sync");
+    failures += (mli::mem::process_default_mode() == mli::mem::Mode::Async) != (DEFAULT_ALLOC_METHOD != 0);
+    std::printf("TOKENS CHECKSUM %016llx\n", checksum);
     std::printf("%s\n", failures ? "FAILED" : "ALL ENGINES AGREE");
     return failures ? 1 : 0;
 }

@@ -21,6 +21,10 @@ void hip_check_last(const char*, int) {}
 namespace mli {
 namespace mem {
 
+static Mode g_default_mode = Mode::Sync;
+void set_process_default_mode(Mode mode) { g_default_mode = mode; }
+Mode process_default_mode() { return g_default_mode; }
+
 struct Block {
     void* ptr;
     std::size_t bytes;

@@ -159,6 +159,57 @@ def test_two_engines_on_private_streams_overlap_safely(oracle, mli, dev):
         e.close()
 
 
+def test_two_engines_with_different_compositions_in_one_process(oracle, mli, dev):
+    """the lean / reference-launch-sequence switch used to be one process-wide flag, so an engine could
+    change what another engine ran mid-flight.  Each engine now carries its own (mli_engine_configure) and installs it for
+    the calling thread only: one engine on the reference's launch sequence and one on the lean compositions, driven by
+    two threads at once, both give the CPU engine's tokens; so does a third engine created while the process default is
+    'reference sequence' and flipped back afterwards."""
+    import threading
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 16, 160, 128, 1024
+    model = make_model(59, V, S, D)
+    items = make_items(60, 48, 1, 60)
+    cpu, _ = run_cpu_engine(oracle, model, items, B, S)
+    engines, outs, errs = [], [None, None, None], []
+    for r, lean in enumerate((0, 1)):
+        e = eng.Engine(eng.PAGED_GEMM, B // 2, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"],
+                       model["wv"], n_blocks=(B // 2) * 5)
+        e.configure(lean_layers=lean)
+        e.use_private_stream()
+        for item_id, toks in items[r::3]:
+            e.add_item(item_id, toks)
+        engines.append(e)
+    mli.mli_engine_set_lean_layers(0)      # the default of engines created from here on ...
+    e = eng.Engine(eng.PAGED, B // 2, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
+                   n_blocks=(B // 2) * 5)
+    mli.mli_engine_set_lean_layers(1)      # ... which must not reach the engines that already exist
+    e.use_private_stream()
+    for item_id, toks in items[2::3]:
+        e.add_item(item_id, toks)
+    engines.append(e)
+
+    def drive(r):
+        try:
+            st = engines[r].run()
+            assert st.finished == len(items[r::3])
+            outs[r] = dict(engines[r].finished())
+        except Exception as ex:
+            errs.append(ex)
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    got = {**outs[0], **outs[1], **outs[2]}
+    for item_id, _ in items:
+        assert len(got[item_id]) == len(cpu[item_id]) and (got[item_id] == cpu[item_id]).all(), item_id
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("kind_name,n_blocks_per_slot", [("PAGED", 4), ("PAGED_GEMM", 4), ("PAGED_GEMM", 8), ("PAGED", 5)])
 def test_pipelined_engine_same_tokens_as_cpu_engine(oracle, mli, dev, kind_name, n_blocks_per_slot):
     """The pipelined loop (host one step behind the GPU, per-slot device updates, one-step-late refill, in-flight

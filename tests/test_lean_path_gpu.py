@@ -128,6 +128,46 @@ def test_lean_scan_equal_page_shares(oracle, mli, dev, seed, B, S, D, lengths, b
     assert_close(outs[0], c["attention_result"], what="attention_result vs oracle")
 
 
+@pytest.mark.parametrize("S,gran", [(1024, 16), (1024, 64), (4096, 16), (2048, 32)])
+def test_lean_scan_equal_page_shares_with_the_largest_dynamic_part(oracle, mli, dev, S, gran):
+    """scan_stream_dynamic_pct at its clamp (60 %): static shares shrink to 6 pages, so a row is cut into the most triples
+    the split can produce -- at most W / min(6, granule) + 4, which launch_stream_decode holds against the W / 4 workspace
+    slots per row before it launches (nothing enforced that bound).  Full rows (L = S - 1) are the worst case."""
+    from min_llm_inference_amd import ops
+    B, D = 40, 128
+    rng = np.random.default_rng(180 + S + gran)
+    lengths = rng.integers(S // 2, S, size=B).astype(np.int32)
+    lengths[:6] = [S - 1, S - 1, S - 2, 0, 1, S - 16]
+    c, d = _prepare(oracle, dev, 181, B, S, D, conditioned=True, lengths=lengths)
+    mli.mli_tune(b"scan_stream", 0)
+    try:
+        ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], None, d["attention_result"], False, phases=7, n_sequence=S)
+        chunked = host(d["attention_result"]).copy()
+        mli.mli_tune(b"scan_stream", 1)
+        assert mli.mli_tune(b"scan_stream_min_tokens", 0) == 0
+        assert mli.mli_tune(b"scan_stream_dynamic_pct", 60) == 0
+        assert mli.mli_tune(b"scan_stream_granule", gran) == 0
+        outs = []
+        for _ in range(3):
+            d["attention_result"].fill_(SENTINEL)
+            ops.decode_scan_paged(d["q_output"], d["page_table"], d["lengths"], None, d["attention_result"], False, phases=7,
+                                  n_sequence=S)
+            outs.append(host(d["attention_result"]).copy())
+    finally:
+        mli.mli_tune(b"scan_stream", 1)
+        mli.mli_tune(b"scan_stream_min_tokens", 1 << 21)
+        mli.mli_tune(b"scan_stream_dynamic_pct", 4)
+        mli.mli_tune(b"scan_stream_granule", 64)
+    assert_equal(outs[1], outs[0], what="second launch")
+    assert_equal(outs[2], outs[0], what="third launch")
+    assert_close(outs[0], chunked, thr=1e-5, what="equal shares (60 % dynamic) vs chunked grid")
+    oracle.qkt_host(c["q_output"], c["kt_cache"], c["lengths"], c["qkt_output"])
+    oracle.softmax_in_place_with_lengths_host(c["qkt_output"], c["lengths"])
+    oracle.softmax_v_host(c["qkt_output"], c["v_cache"], c["attention_result"], c["lengths"])
+    assert_close(outs[0], c["attention_result"], what="attention_result vs oracle")
+    assert (outs[0][3] == 0).all()
+
+
 @pytest.mark.parametrize("chunk,tail", [(64, 0), (128, 0), (256, 0), (512, 64), (512, 128), (1024, 256), (256, 256)])
 def test_lean_scan_many_chunks_per_row(oracle, mli, dev, chunk, tail):
     """Small chunks: up to 64 arrivals per row, rows of every chunk count side by side (uneven load)."""
