@@ -86,6 +86,10 @@ int mli_engine_get_stats(mli_engine* engine, mli_engine_stats* stats);
  * (what a multi-GPU host all-gathers), and its element count. */
 int mli_engine_decoder_result(mli_engine* engine, void** device_ptr, int* count);
 
+/* The stream this engine's kernels run on (hipStream_t as void*; NULL = the legacy default stream): what a multi-GPU host
+ * enqueues the token all-gather on (include/mli_shard.h). */
+int mli_engine_stream(mli_engine* engine, void** stream);
+
 /* Finished item `index` (0 <= index < stats.finished), in completion order: id and tokens (prompt + generated). */
 int mli_engine_get_finished(mli_engine* engine, int index, int* id, int* tokens, int capacity, int* n_tokens);
 

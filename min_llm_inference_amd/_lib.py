@@ -1,4 +1,4 @@
-"""ctypes loader for libmli_hip.so (C ABI: include/mli_kernels.h, include/mli_engine.h)."""
+"""ctypes loader for libmli_hip.so (C ABI: include/mli_kernels.h, include/mli_engine.h, include/mli_shard.h)."""
 import ctypes
 import os
 
@@ -118,8 +118,27 @@ ENGINE_SIGNATURES = {
     "mli_engine_set_lean_layers": [_I],
     "mli_engine_set_step_graphs": [_I],
     "mli_engine_last_error": [],
+    "mli_engine_stream": [_P, _PP],
+    # include/mli_shard.h: the row-sharded engine group (one engine per GPU, RCCL all-gather of the token ids)
+    "mli_shard_group_create": [ctypes.POINTER(EngineConfig), _I, _P, _P, _P, _P, _P, _P, _PP],
+    "mli_shard_group_destroy": [_P],
+    "mli_shard_group_size": [_P],
+    "mli_shard_group_add_item": [_P, _I, _P, _I],
+    "mli_shard_group_run": [_P, _P],
+    "mli_shard_group_gathered": [_P, _I, _PP, _IP],
+    "mli_shard_group_engine": [_P, _I],
+    "mli_shard_last_error": [],
 }
-_RESTYPES = {"mli_attention_workspace_bytes": _Z, "mli_decoder_scratch_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
+
+
+class ShardStats(ctypes.Structure):
+    """mli_shard_stats (include/mli_shard.h)."""
+    _fields_ = [("total_tokens", ctypes.c_longlong), ("seconds", ctypes.c_double), ("iterations", ctypes.c_longlong),
+                ("finished", _I), ("ranks_seen", _I), ("gather_us", ctypes.c_double)]
+
+
+_RESTYPES = {"mli_shard_last_error": ctypes.c_char_p, "mli_shard_group_destroy": None, "mli_shard_group_engine": _P,
+             "mli_attention_workspace_bytes": _Z, "mli_decoder_scratch_bytes": _Z, "mli_engine_last_error": ctypes.c_char_p,
              "mli_engine_destroy": None, "mli_engine_set_lean_layers": None,
              "mli_engine_set_step_graphs": None}
 

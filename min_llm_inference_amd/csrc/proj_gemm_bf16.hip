@@ -467,8 +467,232 @@ __global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs
     }
 }
 
-static thread_local int g_bf16_split = 1;  // mli_tune "gemm_bf16_split": 0 = the 128 x 64 tiled kernel for the large decode projection too
-void set_bf16_split(int v) { g_bf16_split = v != 0; }
+// ---- the same projection with LDS-DMA loaders: one 128 x 192 tile per CU ---------------------------------------------
+// What the kernel above still pays: its loaders move every byte through their registers and a ds_write pass (the write
+// path is the slowest way into LDS and competes with the MFMA waves' fragment reads), two padded buffers of 39 KB leave
+// room for one tile in flight, and 1024 rows x 3 x 2048 columns in 128 x 128 tiles are 384 workgroups = 1.5 per CU.  Here:
+//   * the [Wk | Wq | Wv] columns are one sequence of 64-column sub-tiles and a workgroup takes three of them (192
+//     columns, possibly of two weights): 1024 rows -> 8 x 32 = 256 workgroups, one per CU, dealt so that an XCD's 32
+//     workgroups share 4 column tiles x all row tiles (its L2 sees 3 MB of weights + the rows);
+//   * waves 4-7 only issue global_load_lds_dwordx4 (1 KiB per instruction, no registers, no ds_write): 16 for the A tile
+//     (8 gathered rows x 128 B each), 24 for the B tile (8 k-rows x 128 B of a sub-tile); the LDS image is lane-linear
+//     per instruction, so the bank swizzle is applied to the SOURCE address: A [128 rows][8 chunks of 16 B] with chunk c
+//     stored at c ^ ((row >> 1) & 7) (ds_read_b128 fragment reads conflict-free), B [3][64 k][128 B] with the two 64-byte
+//     halves of a k-row swapped when k & 2 (the 4 k-rows of a ds_read_b64_tr_b16 group land on 4 different bank
+//     quarters) -- unpadded, 40 KiB per stage, three stages: two tiles in flight while the third is multiplied;
+//   * the loaders retire a tile with a counted vmcnt (the younger tile stays in flight) and a raw s_barrier; the MFMA
+//     waves (2 x 2, 64 x 96 each: 6 accumulator tiles, 5 KiB of fragments per 6 MFMAs) read the first fragments of the
+//     next tile right behind that barrier and only then issue the last k sub-step of the previous one.
+// Same 32x32x16 MFMA steps in the same k order as the other two kernels: pages and q_output bit-identical (tested).
+constexpr int kDmThreads = 512;
+constexpr int kDmM = 128, kDmN = 192, kDmK = 64;
+constexpr int kDmABytes = kDmM * kDmK * 2;         // 16384: [128][128 B]
+constexpr int kDmSubBytes = kDmK * 64 * 2;         //  8192: one 64-column sub-tile, [64 k][128 B]
+constexpr int kDmStageBytes = kDmABytes + 3 * kDmSubBytes;   // 40960
+constexpr int kDmStages = 3;
+constexpr int kDmLoadsPerWave = (kDmStageBytes / 1024) / 4;  // 10 DMA instructions per loader wave and tile
+constexpr int kDmTPitch = 96 * 2 + 16;             // epilogue transpose: [64 rows][96 bf16] per wave
+constexpr size_t kDmSmem = (size_t)kDmStages * kDmStageBytes + kDmM * sizeof(void*);
+static_assert(2 * 64 * kDmTPitch <= kDmStageBytes, "two waves' transposes share one stage");
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) void* global_void_ptr;
+
+__device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_dst) {
+    // every lane's 16 bytes go to lds_dst (wave-uniform) + 16 * lane; counted on vmcnt
+    __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)lds_dst, 16, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, int col_tiles, int row_tiles) {
+    static_assert(MODE == kPagedLatest, "decode projection only");
+    extern __shared__ __align__(16) unsigned char dm_smem[];
+    const uint16_t** a_ptr = reinterpret_cast<const uint16_t**>(dm_smem + kDmStages * kDmStageBytes);  // [kDmM]
+
+    // tile of this workgroup.  Workgroups go to the XCDs round-robin: XCD x takes the column tiles
+    // [x * col_tiles / 8, (x + 1) * col_tiles / 8) of every row tile
+    int ct, rt;
+    if (col_tiles % 8 == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cpx = col_tiles >> 3;
+        rt = idx / cpx;
+        ct = xcd * cpx + idx % cpx;
+    } else {
+        rt = blockIdx.x / col_tiles;
+        ct = blockIdx.x % col_tiles;
+    }
+    (void)row_tiles;
+    const int m0 = rt * kDmM;
+    const int subs_per_w = g.N >> 6;   // 64-column sub-tiles per weight matrix
+    const int tid = threadIdx.x;
+    if (tid < kDmM) a_ptr[tid] = reinterpret_cast<const uint16_t*>(resolve_row<MODE, true>(g, m0 + tid, 0, 0).a);
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = g.K / kDmK;
+
+    if (wave >= 4) {
+        // ---------------- loader waves: 4 A + 6 B instructions per tile each ----------------
+        const int lw = wave - 4;
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const unsigned char* src[kDmLoadsPerWave];
+        int dst[kDmLoadsPerWave];
+        int64_t step[kDmLoadsPerWave];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 32 * lw + 8 * i + r8;
+            const uint16_t* p = a_ptr[row];
+            // an empty slot's tile row is never stored: any readable bytes will do (a masked lane would change the
+            // number of DMA instructions in flight, which the counted waits below rely on)
+            if (p == nullptr) p = reinterpret_cast<const uint16_t*>(g.w[0]);
+            src[i] = reinterpret_cast<const unsigned char*>(p) + ((c8 ^ ((row >> 1) & 7)) << 4);
+            dst[i] = (32 * lw + 8 * i) * 128;
+            step[i] = kDmK * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = lw * 6 + i;
+            const int sub = idx >> 3, kb = (idx & 7) * 8;
+            const int k = kb + r8;
+            const int sg = ct * 3 + sub;
+            const unsigned char* W = reinterpret_cast<const unsigned char*>(g.w[sg / subs_per_w]);
+            src[4 + i] = W + ((int64_t)k * g.N + (sg % subs_per_w) * 64) * 2 + ((c8 ^ (((k >> 1) & 1) << 2)) << 4);
+            dst[4 + i] = kDmABytes + sub * kDmSubBytes + kb * 128;
+            step[4 + i] = (int64_t)kDmK * g.N * 2;
+        }
+        auto issue = [&](int t) {
+            unsigned char* stage = dm_smem + (t % kDmStages) * kDmStageBytes;
+#pragma unroll
+            for (int i = 0; i < kDmLoadsPerWave; ++i) {
+                dma16(src[i], stage + dst[i]);
+                src[i] += step[i];
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        for (int t = 0; t < nk; ++t) {
+            // tile t has landed (this wave's part); tile t + 1 may stay in flight
+            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmLoadsPerWave) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // #t: tile t readable; every MFMA wave is done with tile t - 1
+            asm volatile("" ::: "memory");
+            if (t + 2 < nk) issue(t + 2);   // into the stage tile t - 1 occupied
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves: 2 x 2, 64 x 96 each ----------------
+    const int wm = (wave >> 1) * 64;
+    const int wn = (wave & 1) * 96;
+    f32x16_t acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_sw = (li >> 1) & 7;                       // (row >> 1) & 7: wm and mt * 32 are multiples of 16
+    const unsigned a_row_off = (unsigned)((wm + li) * 128);
+    const int tq = (lane >> 2) & 3, tp = lane & 3, g16 = (lane >> 4) & 1;
+    unsigned b_off[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int col = wn + nt * 32;
+        b_off[nt] = (unsigned)(kDmABytes + (col >> 6) * kDmSubBytes + (8 * lh + tq) * 128 +
+                               ((((col >> 5) & 1) * 64 + g16 * 32 + tp * 8) ^ (((tq >> 1) & 1) << 6)));
+    }
+    auto read_frags = [&](const unsigned char* st, int q, Frag8 (&a)[2], Frag8 (&b)[3]) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            b[nt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + q * 16 * 128]));
+            b[nt].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + (q * 16 + 4) * 128]));
+        }
+        const unsigned ac = (unsigned)(((2 * q + lh) ^ a_sw) << 4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt].u = *reinterpret_cast<const uint4*>(&st[a_row_off + mt * 32 * 128 + ac]);
+    };
+    auto multiply = [&](const Frag8 (&a)[2], const Frag8 (&b)[3]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt].v, b[nt].v, acc[mt][nt], 0, 0, 0);
+    };
+    Frag8 fa[2][2], fb[2][3];
+    __syncthreads();  // #0
+    read_frags(dm_smem, 0, fa[0], fb[0]);
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* st = dm_smem + (t % kDmStages) * kDmStageBytes;
+        read_frags(st, 1, fa[1], fb[1]);
+        multiply(fa[0], fb[0]);
+        read_frags(st, 2, fa[0], fb[0]);
+        multiply(fa[1], fb[1]);
+        read_frags(st, 3, fa[1], fb[1]);
+        multiply(fa[0], fb[0]);
+        if (t + 1 < nk) {
+            __syncthreads();  // #(t + 1): every read of tile t is complete (the fence waits for them)
+            read_frags(dm_smem + ((t + 1) % kDmStages) * kDmStageBytes, 0, fa[0], fb[0]);
+        }
+        multiply(fa[1], fb[1]);
+    }
+
+    // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31).
+    // K / V columns go through an LDS transpose (16-byte stores of bf16); the two stages the last tile does not occupy
+    // are free: no DMA is pending and every wave has passed the barrier behind their last reads
+    const int free0 = nk % kDmStages, free1 = (nk + 1) % kDmStages;
+    unsigned char* T = dm_smem + ((wave >> 1) ? free1 : free0) * kDmStageBytes + (wave & 1) * (64 * kDmTPitch);
+    const unsigned long long live = __ballot(a_ptr[wm + lane] != nullptr);   // the wave's 64 rows: which are stored
+    uint16_t* x_row[4];   // the rows this lane stores 16-byte pieces of
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x_row[i] = const_cast<uint16_t*>(a_ptr[wm + i * 16 + (lane >> 2)]);
+    int out_of[3], n_of[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int col = wn + nt * 32;
+        const int sg = ct * 3 + (col >> 6);
+        out_of[nt] = g.out_id[sg / subs_per_w];
+        n_of[nt] = (sg % subs_per_w) * 64 + ((col >> 5) & 1) * 32;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        if (out_of[nt] == 1) {  // q: fp32, 128 contiguous bytes per row and store instruction
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if ((live >> row) & 1) g.q_output[(int64_t)(m0 + wm + row) * g.N + n_of[nt] + li] = acc[mt][nt][r];
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    *reinterpret_cast<uint16_t*>(&T[row * kDmTPitch + (nt * 32 + li) * 2]) = f32_to_bf16(acc[mt][nt][r]);
+                }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave's LDS operations execute in order)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        if (out_of[nt] == 1) continue;
+        const int64_t seg = (int64_t)(out_of[nt] == 0 ? kSegK : kSegV) * g.K;   // element offset from the token's x row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + (lane >> 2), piece = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(&T[row * kDmTPitch + nt * 64 + piece * 16]);
+            if (x_row[i] != nullptr) *reinterpret_cast<uint4*>(x_row[i] + seg + n_of[nt] + piece * 8) = v;
+        }
+    }
+}
+
+static thread_local int g_bf16_split = 2;  // mli_tune "gemm_bf16_split": the large decode projection runs 0 = the 128 x 64
+                                           // tiled kernel, 1 = loader waves + MFMA waves, 2 = LDS-DMA loaders (default)
+void set_bf16_split(int v) { g_bf16_split = v < 0 ? 0 : (v > 2 ? 2 : v); }
 
 int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,
                                     const uint16_t* wq, const uint16_t* wv, float* q, int B, int S, int D,
@@ -482,6 +706,23 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.B = B; g.S = S;
     g.compact = latest_compact(B, D);
     const int tiles_x = ceil_div_i(D, HN) * 3;
+    if (g_bf16_split == 2 && D % 64 == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
+        static std::atomic<unsigned long long> dma_opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device
+        int device = 0;
+        (void)hipGetDevice(&device);
+        const unsigned long long bit = 1ull << (device & 63);
+        if (!(dma_opted_in.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<kPagedLatest>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDmSmem);
+            if (e != hipSuccess) return (int)e;
+            dma_opted_in.fetch_or(bit, std::memory_order_relaxed);
+        }
+        g.compact = 0;  // as below: an empty row's tile rows are never stored
+        const int col_tiles = D / 64, row_tiles = ceil_div_i(B, kDmM);   // 3 weights x D / 192 columns
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<kPagedLatest>), dim3(col_tiles * row_tiles), dim3(kDmThreads), kDmSmem, st,
+                           g, col_tiles, row_tiles);
+        return launch_status();
+    }
     if (g_bf16_split && D % kSpN == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
         static std::atomic<unsigned long long> opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device
         int device = 0;

@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import EngineConfig, EngineStats, MliError, load_library
+from ._lib import EngineConfig, EngineStats, MliError, ShardStats, load_library
 
 CONTIGUOUS, PAGED, PAGED_GEMM, PAGED_BF16 = 0, 1, 2, 3  # PAGED_BF16: extension, bf16 pages and weights
 PAGED_FP8 = 4  # extension, opt-in: fp8 (OCP e4m3) pages, bf16 weights
@@ -85,6 +85,68 @@ class Engine:
     def close(self):
         if self._h:
             self._lib.mli_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BorrowedEngine(Engine):
+    """An engine owned by a ShardGroup: same accessors, never destroyed from here."""
+
+    def __init__(self, lib, handle, cfg):
+        self._lib, self._h, self.cfg = lib, ctypes.c_void_p(handle), cfg
+
+    def close(self):
+        self._h = ctypes.c_void_p()
+
+
+class ShardGroup:
+    """include/mli_shard.h: one engine per GPU inside this process (one host thread each), stepped in lock step with one RCCL
+    all-gather of the generated token ids per rank and iteration.  `n_batch` / `n_blocks` are PER RANK."""
+
+    def __init__(self, kind, n_batch, n_sequence, emb_dim, n_vocab, emb_table, pos_table, wk, wq, wv, devices, n_blocks=0,
+                 n_forward_rounds=1):
+        self._lib = load_library()
+        self.devices = [int(d) for d in devices]
+        self.cfg = EngineConfig(kind, n_batch, n_sequence, emb_dim, n_vocab, n_blocks, n_forward_rounds, 0, 0)
+        keep = [_fp(x) for x in (emb_table, pos_table, wk, wq, wv)]
+        dev = np.asarray(self.devices, dtype=np.int32)
+        self._h = ctypes.c_void_p()
+        self._check(self._lib.mli_shard_group_create(ctypes.byref(self.cfg), len(self.devices),
+                                                     dev.ctypes.data_as(ctypes.c_void_p), *[k[1] for k in keep],
+                                                     ctypes.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MliError("Hip Failure: " + (self._lib.mli_shard_last_error() or b"").decode())
+
+    def add_item(self, item_id, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._check(self._lib.mli_shard_group_add_item(self._h, int(item_id), t.ctypes.data_as(ctypes.c_void_p), len(t)))
+
+    def run(self):
+        st = ShardStats()
+        self._check(self._lib.mli_shard_group_run(self._h, ctypes.byref(st)))
+        return st
+
+    def gathered_ptr(self, rank):
+        p, n = ctypes.c_void_p(), ctypes.c_int()
+        self._check(self._lib.mli_shard_group_gathered(self._h, rank, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def engine(self, rank):
+        h = self._lib.mli_shard_group_engine(self._h, rank)
+        if not h:
+            raise MliError("no such rank")
+        return _BorrowedEngine(self._lib, h, self.cfg)
+
+    def close(self):
+        if self._h:
+            self._lib.mli_shard_group_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -375,6 +375,13 @@ int mli_engine_decoder_result(mli_engine* e, void** device_ptr, int* count) {
     })
 }
 
+int mli_engine_stream(mli_engine* e, void** stream) {
+    MLI_GUARD({
+        if (!e || !stream) throw std::runtime_error("null argument");
+        *stream = e->stream;
+    })
+}
+
 int mli_engine_get_finished(mli_engine* e, int index, int* id, int* tokens, int capacity, int* n_tokens) {
     MLI_GUARD({
         const auto& items = e->item_storage.get_finished_items();

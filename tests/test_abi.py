@@ -15,7 +15,7 @@ def _declared(header):
 
 
 def test_library_exports_every_declared_symbol(mli):
-    names = _declared("mli_kernels.h") + _declared("mli_engine.h")
+    names = _declared("mli_kernels.h") + _declared("mli_engine.h") + _declared("mli_shard.h")
     assert len(set(names)) >= 19
     for n in set(names):
         assert hasattr(mli, n), f"libmli_hip.so does not export {n}"
@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(mli):
 def test_binding_table_matches_header():
     from min_llm_inference_amd import _lib
     declared = set(_declared("mli_kernels.h"))
-    bound = {n for n in _lib.SIGNATURES if not n.startswith("mli_engine")}
+    bound = {n for n in _lib.SIGNATURES if not n.startswith(("mli_engine", "mli_shard"))}
     assert declared == bound, (declared ^ bound)
 
 

@@ -11,12 +11,13 @@ fn = [v for k, v in wl.kernels().items() if k.startswith("get_latest")][0]
 flops = 2.0 * wl.B * wl.D * 3 * wl.D
 out = {}
 for rnd in range(3):
-    for split in (0, 1):
+    for split in (0, 1, 2):
         lib.mli_tune(b"gemm_bf16_split", split)
         t = bench.time_kernel(fn, 200)
         out.setdefault(f"split{split}", []).append((round(t * 1e3, 1), round(flops / (t * 1e-3) / 1e12)))
 # same results?
 lib.mli_tune(b"gemm_bf16_split", 0); fn(); torch.cuda.synchronize(); q0 = wl.q_output.clone(); p0 = wl.pool.clone()
-lib.mli_tune(b"gemm_bf16_split", 1); wl.q_output.zero_(); fn(); torch.cuda.synchronize()
-out["identical"] = bool(torch.equal(q0, wl.q_output) and torch.equal(p0.view(torch.int16), wl.pool.view(torch.int16)))
+for split in (1, 2):
+    lib.mli_tune(b"gemm_bf16_split", split); wl.q_output.zero_(); fn(); torch.cuda.synchronize()
+    out[f"identical{split}"] = bool(torch.equal(q0, wl.q_output) and torch.equal(p0.view(torch.int16), wl.pool.view(torch.int16)))
 print(json.dumps(out))
