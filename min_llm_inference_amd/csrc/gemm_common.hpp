@@ -150,9 +150,11 @@ struct RowDesc {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     // round to nearest even; NaN stays NaN (integer rounding alone would turn some NaNs into Inf/0)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    // (both results, one select: as an early return this is a branch per element in unrolled epilogues)
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t nan = (u >> 16) | 0x0040u;
+    const uint32_t rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (uint16_t)((u & 0x7fffffffu) > 0x7f800000u ? nan : rne);
 }
 __device__ __forceinline__ float4 load4_bf16(const void* p) {  // 4 consecutive bf16 (8 bytes)
     const uint2 v = *reinterpret_cast<const uint2*>(p);

@@ -14,6 +14,7 @@
 //     barrier pair instead of 2) for the decode projection of a large batch at a large emb_dim, where the small
 //     tile spends its time on staging and barriers (B=1024, D=2048: 451 TFLOP/s).
 #include <atomic>
+#include <cstdlib>
 
 #include "gemm_common.hpp"
 
@@ -485,15 +486,26 @@ __global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs
 //     next tile right behind that barrier and only then issue the last k sub-step of the previous one.
 // Same 32x32x16 MFMA steps in the same k order as the other two kernels: pages and q_output bit-identical (tested).
 constexpr int kDmThreads = 512;
-constexpr int kDmM = 128, kDmN = 192, kDmK = 64;
+constexpr int kDmM = 128, kDmK = 64;   // (x 192 columns = three 64-column sub-tiles)
 constexpr int kDmABytes = kDmM * kDmK * 2;         // 16384: [128][128 B]
 constexpr int kDmSubBytes = kDmK * 64 * 2;         //  8192: one 64-column sub-tile, [64 k][128 B]
 constexpr int kDmStageBytes = kDmABytes + 3 * kDmSubBytes;   // 40960
 constexpr int kDmStages = 3;
 constexpr int kDmLoadsPerWave = (kDmStageBytes / 1024) / 4;  // 10 DMA instructions per loader wave and tile
-constexpr int kDmTPitch = 96 * 2 + 16;             // epilogue transpose: [64 rows][96 bf16] per wave
+constexpr int kDmOutSubBytes = kDmM * 64 * 4;      // epilogue: one 64-column sub-tile of the output, fp32 at most
 constexpr size_t kDmSmem = (size_t)kDmStages * kDmStageBytes + kDmM * sizeof(void*);
-static_assert(2 * 64 * kDmTPitch <= kDmStageBytes, "two waves' transposes share one stage");
+static_assert(3 * kDmOutSubBytes <= kDmStages * kDmStageBytes, "the output tile reuses the stages");
+
+// -DMLI_DMA_TRACE: where a workgroup of the kernel below spends its cycles (tools/gemm_dma_trace.py) -- never the product
+#ifdef MLI_DMA_TRACE
+constexpr int kDmaTraceWgs = 1024;
+__device__ unsigned long long mli_dma_trace[kDmaTraceWgs * 16];
+#define MLI_DT(var) const unsigned long long var = clock64()
+#define MLI_DT_PUT(i, v) do { if (blockIdx.x < (unsigned)kDmaTraceWgs) mli_dma_trace[blockIdx.x * 16 + (i)] = (v); } while (0)
+#else
+#define MLI_DT(var) do { } while (0)
+#define MLI_DT_PUT(i, v) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) void* global_void_ptr;
@@ -524,31 +536,21 @@ __global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, i
     const int m0 = rt * kDmM;
     const int subs_per_w = g.N >> 6;   // 64-column sub-tiles per weight matrix
     const int tid = threadIdx.x;
-    if (tid < kDmM) a_ptr[tid] = reinterpret_cast<const uint16_t*>(resolve_row<MODE, true>(g, m0 + tid, 0, 0).a);
-    __syncthreads();
-
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = g.K / kDmK;
+    MLI_DT(dt_entry);
+#ifdef MLI_DMA_TRACE
+    const unsigned long long dt_wall0 = wall_clock64();   // 100 MHz: what a clock64() tick is worth under this load
+#endif
 
     if (wave >= 4) {
         // ---------------- loader waves: 4 A + 6 B instructions per tile each ----------------
         const int lw = wave - 4;
         const int r8 = lane >> 3, c8 = lane & 7;
-        const unsigned char* src[kDmLoadsPerWave];
+        const unsigned char* src[kDmLoadsPerWave];   // [0, 6): B, [6, 10): A
         int dst[kDmLoadsPerWave];
-        int64_t step[kDmLoadsPerWave];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 32 * lw + 8 * i + r8;
-            const uint16_t* p = a_ptr[row];
-            // an empty slot's tile row is never stored: any readable bytes will do (a masked lane would change the
-            // number of DMA instructions in flight, which the counted waits below rely on)
-            if (p == nullptr) p = reinterpret_cast<const uint16_t*>(g.w[0]);
-            src[i] = reinterpret_cast<const unsigned char*>(p) + ((c8 ^ ((row >> 1) & 7)) << 4);
-            dst[i] = (32 * lw + 8 * i) * 128;
-            step[i] = kDmK * 2;
-        }
+        const int64_t b_step = (int64_t)kDmK * g.N * 2;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int idx = lw * 6 + i;
@@ -556,138 +558,245 @@ __global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, i
             const int k = kb + r8;
             const int sg = ct * 3 + sub;
             const unsigned char* W = reinterpret_cast<const unsigned char*>(g.w[sg / subs_per_w]);
-            src[4 + i] = W + ((int64_t)k * g.N + (sg % subs_per_w) * 64) * 2 + ((c8 ^ (((k >> 1) & 1) << 2)) << 4);
-            dst[4 + i] = kDmABytes + sub * kDmSubBytes + kb * 128;
-            step[4 + i] = (int64_t)kDmK * g.N * 2;
+            src[i] = W + ((int64_t)k * g.N + (sg % subs_per_w) * 64) * 2 + ((c8 ^ (((k >> 1) & 1) << 2)) << 4);
+            dst[i] = kDmABytes + sub * kDmSubBytes + kb * 128;
         }
-        auto issue = [&](int t) {
+        auto issue_b = [&](int t) {
             unsigned char* stage = dm_smem + (t % kDmStages) * kDmStageBytes;
 #pragma unroll
-            for (int i = 0; i < kDmLoadsPerWave; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 dma16(src[i], stage + dst[i]);
-                src[i] += step[i];
+                src[i] += b_step;
             }
         };
-        issue(0);
-        if (nk > 1) issue(1);
+        auto issue_a = [&](int t) {
+            unsigned char* stage = dm_smem + (t % kDmStages) * kDmStageBytes;
+#pragma unroll
+            for (int i = 6; i < kDmLoadsPerWave; ++i) {
+                dma16(src[i], stage + dst[i]);
+                src[i] += kDmK * 2;
+            }
+        };
+        // the weights of the first two tiles travel while waves 0-1 look the rows up (raw barrier: a __syncthreads() would
+        // wait for them)
+        issue_b(0);
+        if (nk > 1) issue_b(1);
+        __builtin_amdgcn_s_barrier();   // the row pointers are in LDS
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 32 * lw + 8 * i + r8;
+            const uint16_t* p = a_ptr[row];
+            // an empty slot's tile row is never stored: any readable bytes will do (a masked lane would change the
+            // number of DMA instructions in flight, which the counted waits below rely on)
+            if (p == nullptr) p = reinterpret_cast<const uint16_t*>(g.w[0]);
+            src[6 + i] = reinterpret_cast<const unsigned char*>(p) + ((c8 ^ ((row >> 1) & 7)) << 4);
+            dst[6 + i] = (32 * lw + 8 * i) * 128;
+        }
+        issue_a(0);
+        if (nk > 1) issue_a(1);
+#ifdef MLI_DMA_TRACE
+        unsigned long long dt_wait = 0, dt_bar = 0, dt_issue = 0;
+#endif
         for (int t = 0; t < nk; ++t) {
-            // tile t has landed (this wave's part); tile t + 1 may stay in flight
-            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmLoadsPerWave) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile t has landed (this wave's part); tile t + 1 may stay in flight.  In issue order the queue holds
+            // B0 B1 A0 A1 before the loop (t = 0: everything but A1 must be done) and [tile t: 10][tile t + 1: 10] afterwards
+            MLI_DT(l0);
+#ifdef MLI_DMA_TRACE
+            if (g.n_new & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            if (t + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (t == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmLoadsPerWave) : "memory");
+            MLI_DT(l1);
             __builtin_amdgcn_s_barrier();   // #t: tile t readable; every MFMA wave is done with tile t - 1
             asm volatile("" ::: "memory");
-            if (t + 2 < nk) issue(t + 2);   // into the stage tile t - 1 occupied
+            MLI_DT(l2);
+#ifdef MLI_DMA_TRACE
+            if (g.n_new & 1) continue;   // debug: nothing is loaded after the first two tiles (the MFMA waves multiply stale bytes)
+#endif
+            if (t + 2 < nk) {   // into the stage tile t - 1 occupied
+                issue_b(t + 2);
+                issue_a(t + 2);
+            }
+#ifdef MLI_DMA_TRACE
+            const unsigned long long l3 = clock64();
+            dt_wait += l1 - l0; dt_bar += l2 - l1; dt_issue += l3 - l2;
+#endif
         }
-        return;
-    }
-
-    // ---------------- MFMA waves: 2 x 2, 64 x 96 each ----------------
-    const int wm = (wave >> 1) * 64;
-    const int wn = (wave & 1) * 96;
-    f32x16_t acc[2][3];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-    const int li = lane & 31, lh = lane >> 5;
-    const int a_sw = (li >> 1) & 7;                       // (row >> 1) & 7: wm and mt * 32 are multiples of 16
-    const unsigned a_row_off = (unsigned)((wm + li) * 128);
-    const int tq = (lane >> 2) & 3, tp = lane & 3, g16 = (lane >> 4) & 1;
-    unsigned b_off[3];
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        const int col = wn + nt * 32;
-        b_off[nt] = (unsigned)(kDmABytes + (col >> 6) * kDmSubBytes + (8 * lh + tq) * 128 +
-                               ((((col >> 5) & 1) * 64 + g16 * 32 + tp * 8) ^ (((tq >> 1) & 1) << 6)));
-    }
-    auto read_frags = [&](const unsigned char* st, int q, Frag8 (&a)[2], Frag8 (&b)[3]) {
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            b[nt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + q * 16 * 128]));
-            b[nt].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + (q * 16 + 4) * 128]));
-        }
-        const unsigned ac = (unsigned)(((2 * q + lh) ^ a_sw) << 4);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a[mt].u = *reinterpret_cast<const uint4*>(&st[a_row_off + mt * 32 * 128 + ac]);
-    };
-    auto multiply = [&](const Frag8 (&a)[2], const Frag8 (&b)[3]) {
+#ifdef MLI_DMA_TRACE
+        if (tid == 256) { MLI_DT_PUT(8, dt_wait); MLI_DT_PUT(9, dt_bar); MLI_DT_PUT(10, dt_issue); }
+#endif
+        __builtin_amdgcn_s_barrier();   // E1: (the MFMA waves are done with the last tile)
+        __builtin_amdgcn_s_barrier();   // E2: the output tile is in LDS
+        asm volatile("" ::: "memory");
+    } else {
+        // ---------------- MFMA waves: 2 x 2, 64 x 96 each ----------------
+        if (tid < kDmM) a_ptr[tid] = reinterpret_cast<const uint16_t*>(resolve_row<MODE, true>(g, m0 + tid, 0, 0).a);
+        __syncthreads();   // (pairs with the loaders' first barrier)
+        MLI_DT(dt_rows);
+        const int wm = (wave >> 1) * 64;
+        const int wn = (wave & 1) * 96;
+        f32x16_t acc[2][3];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt].v, b[nt].v, acc[mt][nt], 0, 0, 0);
-    };
-    Frag8 fa[2][2], fb[2][3];
-    __syncthreads();  // #0
-    read_frags(dm_smem, 0, fa[0], fb[0]);
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* st = dm_smem + (t % kDmStages) * kDmStageBytes;
-        read_frags(st, 1, fa[1], fb[1]);
-        multiply(fa[0], fb[0]);
-        read_frags(st, 2, fa[0], fb[0]);
-        multiply(fa[1], fb[1]);
-        read_frags(st, 3, fa[1], fb[1]);
-        multiply(fa[0], fb[0]);
-        if (t + 1 < nk) {
-            __syncthreads();  // #(t + 1): every read of tile t is complete (the fence waits for them)
-            read_frags(dm_smem + ((t + 1) % kDmStages) * kDmStageBytes, 0, fa[0], fb[0]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        const int li = lane & 31, lh = lane >> 5;
+        const int a_sw = (li >> 1) & 7;                       // (row >> 1) & 7: wm and mt * 32 are multiples of 16
+        const unsigned a_row_off = (unsigned)((wm + li) * 128);
+        const int tq = (lane >> 2) & 3, tp = lane & 3, g16 = (lane >> 4) & 1;
+        unsigned b_off[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int col = wn + nt * 32;
+            b_off[nt] = (unsigned)(kDmABytes + (col >> 6) * kDmSubBytes + (8 * lh + tq) * 128 +
+                                   ((((col >> 5) & 1) * 64 + g16 * 32 + tp * 8) ^ (((tq >> 1) & 1) << 6)));
         }
-        multiply(fa[1], fb[1]);
+        // in the order the MFMAs want them: (a0, b0), b1, b2, a1
+        auto read_frags = [&](const unsigned char* st, int q, Frag8 (&a)[2], Frag8 (&b)[3]) {
+            const unsigned ac = (unsigned)(((2 * q + lh) ^ a_sw) << 4);
+            a[0].u = *reinterpret_cast<const uint4*>(&st[a_row_off + ac]);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                b[nt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + q * 16 * 128]));
+                b[nt].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&st[b_off[nt] + (q * 16 + 4) * 128]));
+            }
+            a[1].u = *reinterpret_cast<const uint4*>(&st[a_row_off + 32 * 128 + ac]);
+        };
+        auto multiply = [&](const Frag8 (&a)[2], const Frag8 (&b)[3]) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt].v, b[nt].v, acc[mt][nt], 0, 0, 0);
+        };
+        // one k sub-step: the 8 fragment reads of the NEXT sub-step go out between the first MFMAs of this one (2 per MFMA),
+        // so that they have the rest of the sub-step to land; left alone the compiler issues them right in front of their use
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 LDS reads
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        };
+        Frag8 fa[2][2], fb[2][3];
+        __syncthreads();  // #0
+        MLI_DT(dt_first);
+#ifdef MLI_DMA_TRACE
+        unsigned long long dt_mbar = 0;
+#endif
+        read_frags(dm_smem, 0, fa[0], fb[0]);
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* st = dm_smem + (t % kDmStages) * kDmStageBytes;
+            read_frags(st, 1, fa[1], fb[1]);
+            multiply(fa[0], fb[0]);
+            interleave();
+            read_frags(st, 2, fa[0], fb[0]);
+            multiply(fa[1], fb[1]);
+            interleave();
+            read_frags(st, 3, fa[1], fb[1]);
+            multiply(fa[0], fb[0]);
+            interleave();
+            if (t + 1 < nk) {
+                MLI_DT(m0t);
+                __syncthreads();  // #(t + 1): every read of tile t is complete (the fence waits for them)
+#ifdef MLI_DMA_TRACE
+                dt_mbar += clock64() - m0t;
+#endif
+                read_frags(dm_smem + ((t + 1) % kDmStages) * kDmStageBytes, 0, fa[0], fb[0]);
+            }
+            multiply(fa[1], fb[1]);
+        }
+        MLI_DT(dt_loop_end);
+#ifdef MLI_DMA_TRACE
+        if (tid == 0) {
+            MLI_DT_PUT(0, dt_entry); MLI_DT_PUT(1, dt_rows); MLI_DT_PUT(2, dt_first); MLI_DT_PUT(3, dt_loop_end);
+            MLI_DT_PUT(5, dt_mbar);
+        }
+#endif
+        // the output tile goes to LDS as fp32 (no DMA is pending; E1: every wave is done with the last tile): per 64-column
+        // sub-tile [128 rows][64 floats].  Register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
+        __syncthreads();   // E1
+#ifdef MLI_DMA_TRACE
+        if (tid == 0) MLI_DT_PUT(11, clock64());
+#endif
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int col = wn + nt * 32;
+            unsigned char* C = dm_smem + (col >> 6) * kDmOutSubBytes + (((col >> 5) & 1) * 32 + li) * 4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(&C[(wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 256]) = acc[mt][nt][r];
+        }
+        __syncthreads();   // E2
+#ifdef MLI_DMA_TRACE
+        if (tid == 0) MLI_DT_PUT(12, clock64());
+#endif
     }
 
-    // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31).
-    // K / V columns go through an LDS transpose (16-byte stores of bf16); the two stages the last tile does not occupy
-    // are free: no DMA is pending and every wave has passed the barrier behind their last reads
-    const int free0 = nk % kDmStages, free1 = (nk + 1) % kDmStages;
-    unsigned char* T = dm_smem + ((wave >> 1) ? free1 : free0) * kDmStageBytes + (wave & 1) * (64 * kDmTPitch);
-    const unsigned long long live = __ballot(a_ptr[wm + lane] != nullptr);   // the wave's 64 rows: which are stored
-    uint16_t* x_row[4];   // the rows this lane stores 16-byte pieces of
+    // all 8 waves: whole rows of a sub-tile leave as 16-byte stores -- 256 contiguous bytes per q row (4 rows per
+    // instruction), 128 per K / V row (8 rows per instruction).  Every piece is read into its own registers before the first
+    // store goes out: a register that a store in flight still reads cannot be reloaded without waiting for that store
+    const uint16_t* q_row[4];
+    const uint16_t* kv_row[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_row[i] = const_cast<uint16_t*>(a_ptr[wm + i * 16 + (lane >> 2)]);
-    int out_of[3], n_of[3];
+    for (int i = 0; i < 4; ++i) q_row[i] = a_ptr[wave * 16 + i * 4 + (lane >> 4)];
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        const int col = wn + nt * 32;
-        const int sg = ct * 3 + (col >> 6);
-        out_of[nt] = g.out_id[sg / subs_per_w];
-        n_of[nt] = (sg % subs_per_w) * 64 + ((col >> 5) & 1) * 32;
-    }
+    for (int i = 0; i < 2; ++i) kv_row[i] = a_ptr[wave * 16 + i * 8 + (lane >> 3)];
+    // (a wave-uniform choice per sub-tile.)  q: 4 rows per instruction, 16 lanes x 16 bytes each; K / V: a lane turns 8
+    // floats into 8 bf16 -- 8 rows per instruction, 8 lanes x 16 bytes each
+    auto load_sub = [&](int sub, uint4 (&v)[4]) -> int {
+        const int out_id = g.out_id[(ct * 3 + sub) / subs_per_w];
+        const unsigned char* C = dm_smem + sub * kDmOutSubBytes;
+        if (out_id == 1) {
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        if (out_of[nt] == 1) {  // q: fp32, 128 contiguous bytes per row and store instruction
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if ((live >> row) & 1) g.q_output[(int64_t)(m0 + wm + row) * g.N + n_of[nt] + li] = acc[mt][nt][r];
-                }
+            for (int i = 0; i < 4; ++i)
+                v[i] = *reinterpret_cast<const uint4*>(&C[(wave * 16 + i * 4 + (lane >> 4)) * 256 + (lane & 15) * 16]);
         } else {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    *reinterpret_cast<uint16_t*>(&T[row * kDmTPitch + (nt * 32 + li) * 2]) = f32_to_bf16(acc[mt][nt][r]);
-                }
+            for (int i = 0; i < 4; ++i)
+                v[i] = *reinterpret_cast<const uint4*>(&C[(wave * 16 + (i >> 1) * 8 + (lane >> 3)) * 256 + (lane & 7) * 32 + (i & 1) * 16]);
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave's LDS operations execute in order)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return out_id;
+    };
+    auto pack2 = [](uint32_t a, uint32_t b) { return (uint32_t)f32_to_bf16(__uint_as_float(a)) | ((uint32_t)f32_to_bf16(__uint_as_float(b)) << 16); };
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) u32x4_t* global_u32x4_ptr;
+    auto store_sub = [&](int sub, int out_id, const uint4 (&v)[4]) {
+        const int n = ((ct * 3 + sub) % subs_per_w) * 64;
+        if (out_id == 1) {
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        if (out_of[nt] == 1) continue;
-        const int64_t seg = (int64_t)(out_of[nt] == 0 ? kSegK : kSegV) * g.K;   // element offset from the token's x row
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 16 + i * 4 + (lane >> 4);
+                if (q_row[i] != nullptr)
+                    *(global_u32x4_ptr)(g.q_output + (int64_t)(m0 + row) * g.N + n + (lane & 15) * 4) = u32x4_t{v[i].x, v[i].y, v[i].z, v[i].w};
+            }
+        } else {
+            const int64_t seg = (int64_t)(out_id == 0 ? kSegK : kSegV) * g.K;   // element offset from the token's x row
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 16 + (lane >> 2), piece = lane & 3;
-            const uint4 v = *reinterpret_cast<const uint4*>(&T[row * kDmTPitch + nt * 64 + piece * 16]);
-            if (x_row[i] != nullptr) *reinterpret_cast<uint4*>(x_row[i] + seg + n_of[nt] + piece * 8) = v;
+            for (int i = 0; i < 2; ++i) {
+                const u32x4_t w{pack2(v[2 * i].x, v[2 * i].y), pack2(v[2 * i].z, v[2 * i].w),
+                                pack2(v[2 * i + 1].x, v[2 * i + 1].y), pack2(v[2 * i + 1].z, v[2 * i + 1].w)};
+                if (kv_row[i] != nullptr) *(global_u32x4_ptr)(const_cast<uint16_t*>(kv_row[i]) + seg + n + (lane & 7) * 8) = w;
+            }
         }
-    }
+    };
+    uint4 v0[4], v1[4], v2[4];
+    const int o0 = load_sub(0, v0), o1 = load_sub(1, v1), o2 = load_sub(2, v2);
+    store_sub(0, o0, v0);
+    store_sub(1, o1, v1);
+    store_sub(2, o2, v2);
+#ifdef MLI_DMA_TRACE
+    if (tid == 0) MLI_DT_PUT(13, clock64());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { MLI_DT_PUT(4, clock64()); MLI_DT_PUT(6, wall_clock64() - dt_wall0); }
+#endif
 }
 
 static thread_local int g_bf16_split = 2;  // mli_tune "gemm_bf16_split": the large decode projection runs 0 = the 128 x 64
@@ -718,6 +827,9 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
             dma_opted_in.fetch_or(bit, std::memory_order_relaxed);
         }
         g.compact = 0;  // as below: an empty row's tile rows are never stored
+#ifdef MLI_DMA_TRACE
+        if (const char* dbg = std::getenv("MLI_DMA_DEBUG")) g.n_new = std::atoi(dbg);
+#endif
         const int col_tiles = D / 64, row_tiles = ceil_div_i(B, kDmM);   // 3 weights x D / 192 columns
         hipLaunchKernelGGL((gemm_bf16_dma_kernel<kPagedLatest>), dim3(col_tiles * row_tiles), dim3(kDmThreads), kDmSmem, st,
                            g, col_tiles, row_tiles);
@@ -828,6 +940,13 @@ int launch_fill_paged_bf16_native(uint16_t* const* page_table, const int* new_id
 }
 
 }  // namespace mli
+
+#ifdef MLI_DMA_TRACE
+extern "C" int mli_debug_dma_trace(unsigned long long* host, int n_wgs) {
+    if (n_wgs > mli::kDmaTraceWgs) n_wgs = mli::kDmaTraceWgs;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mli::mli_dma_trace), (size_t)n_wgs * 16 * sizeof(unsigned long long));
+}
+#endif
 
 #ifdef MLI_GEMM_TRACE
 extern "C" int mli_debug_gemm_trace(unsigned long long* host, int n_wgs) {
