@@ -415,15 +415,22 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
         return None, None
     kernels = json.load(open(path))["kernels"]
     needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan", "scan_lean": "fused_decode_s"}[which]
-    # the chunked scan kernel's last template argument says whether it writes the raw scores ("..., true>" / "..., false>");
-    # the equal-shares kernel (fused_decode_stream_kernel) exists in the lean form only
+    # the chunked scan kernel's template arguments end in "..., SCORES, RPI>": SCORES says whether it writes the raw scores
+    # (the materialising form); the equal-shares kernel (fused_decode_stream_kernel) exists in the lean form only
+    import re
+
+    def scores_flag(name):
+        m = re.search(r",\s*(true|false)(?:,\s*\d+)?>\s*$", name)
+        return m.group(1) if m else None
+
     if which == "scan_lean":
         hits = [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_stream" in k] or \
-               [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_scan" in k and k.endswith(", false>")] or \
+               [v["traffic_bytes"] for k, v in kernels.items() if "fused_decode_scan" in k and scores_flag(k) == "false"] or \
                [v["traffic_bytes"] for k, v in kernels.items() if "naive_decode_scan" in k]
+    elif which == "scan":
+        hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and scores_flag(k) == "true"]
     else:
-        tail = ", true>" if which == "scan" else ""
-        hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and k.endswith(tail)]
+        hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k]
     return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
 
 

@@ -293,7 +293,10 @@ int mli_paged_decoder_fused(const float* batch_result, const float* emb_table, c
  *   mli_inference_optimized_encoder + mli_fill_new_kt_v_cache                   (contiguous)
  * i.e. launch_paged_attention_encoder_kernel + launch_fill_new_k_v_cache_paged_attention[_warp_tiling]
  * (encoder.h:22-25, paged_attention.h:28-30,65-67) resp. launch_inference_optimized_encoder_kernel +
- * launch_fill_new_kt_v_cache (encoder.h:16-19, self_attention_inference_optimized.h:5-8).  No-op when n_new_items == 0. */
+ * launch_fill_new_kt_v_cache (encoder.h:16-19, self_attention_inference_optimized.h:5-8).  No-op when n_new_items == 0.
+ * Since round 3 the entry points pick the form by shape (mli_tune "prefill_fused"): the prologue form up to emb_dim 512, those
+ * two launches beyond -- every column tile of the prologue form re-reads the fp32 embedding and position rows, which wide
+ * models (many column tiles) pay more for than for one launch boundary (emb_dim 2048: 199 us against 154 + 14 us). */
 int mli_paged_prefill(const float* emb_table, const float* wpe, const int* inp, void* const* page_table,
                       const int* lengths, const int* new_item_indices, const void* wk, const void* wv,
                       int n_batch, int n_sequence, int emb_dim, int n_new_items, int elem_bf16, void* stream);
@@ -401,6 +404,9 @@ int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream);
  *   "gemm_bf16_split"  the bf16 decode projection of a large batch (>= 1024 rows, emb_dim >= 1024): 2 (default) = LDS-DMA
  *                      loader waves + MFMA waves, one 128 x 192 tile per CU (emb_dim a multiple of 64), 1 = register-staging
  *                      loader waves, 128 x 128 tiles (a multiple of 128), 0 = the 128 x 64 tiled kernel (identical results)
+ *   "prefill_fused"    1 (default) = mli_[paged_]prefill runs the encoder as the fill GEMM's prologue up to emb_dim 512 and
+ *                      encoder + fill as two launches beyond, 0 = always two launches, 2 = always the prologue form (fp8 pages
+ *                      have the prologue form only); pages / caches are bit-identical either way
  *   "gemm_panel"       1 (default) = small fp32 products (emb_dim <= 512, fewer than 256 tiles of 64x64: the decode
  *                      projection and the logits of configs 2 / 3) run the latency-shaped kernel (32x32 tiles, the
  *                      whole K panel requested at once), 0 = always the tiled kernel, 2 = whenever the shape allows

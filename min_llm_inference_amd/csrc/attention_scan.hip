@@ -35,6 +35,7 @@ void set_partial_last(int v);
 void set_gemm_split(int v);
 void set_row_order(int v);
 void set_bf16_split(int v);
+void set_prefill_fused(int v);
 void set_naive_fused(int v);
 void set_gemm_tall_tiles(int v);
 void set_deep_k_tiles(int v);
@@ -730,6 +731,8 @@ int mli_tune(const char* key, int value) {
         mli::set_naive_fused(value);
     } else if (k == "gemm_bf16_split") {
         mli::set_bf16_split(value);
+    } else if (k == "prefill_fused") {
+        mli::set_prefill_fused(value);
     } else if (k == "scan_row_order") {
         mli::set_row_order(value);
     } else if (k == "gemm_split") {

@@ -38,6 +38,7 @@ int launch_fill_paged_embed(const float*, const float*, const int*, float* const
                             const float*, int, int, int, int, hipStream_t);
 int launch_fill_paged_bf16_embed(const float*, const float*, const int*, uint16_t* const*, const int*, const int*,
                                  const uint16_t*, const uint16_t*, int, int, int, int, hipStream_t);
+bool prefill_fuses(int emb_dim);   // proj_gemm.hip: mli_tune "prefill_fused"
 // single-launch scan over the contiguous caches (attention_fused_naive.hip): 1 = ran, 0 = shape not covered, else error + (rc > 0)
 int launch_fused_decode_naive(const float*, const float*, const float*, const int*, float*, int, int, int, void*, size_t,
                               hipStream_t);
@@ -179,6 +180,26 @@ int mli_paged_prefill(const float* emb_table, const float* wpe, const int* inp, 
         return mli::launch_fill_paged_fp8_embed(emb_table, wpe, inp, reinterpret_cast<uint8_t* const*>(page_table),
                                                 new_item_indices, lengths, static_cast<const mli_bf16*>(wk),
                                                 static_cast<const mli_bf16*>(wv), n_batch, n_sequence, emb_dim, n_new_items, st);
+    // The prologue form reads emb_table and wpe (fp32, 8 bytes per element) in EVERY column tile instead of the 2- or
+    // 4-byte x element: worth one launch boundary and the x round trip while there are few column tiles, a loss beyond
+    // (emb_dim 2048: 64 column tiles, 199 us against 154 + 14 us for encoder + fill; emb_dim 256: 8 tiles, a gain) -- so
+    // wide models take the two launches.  Pages are bit-identical either way (tested).
+    if (!mli::prefill_fuses(emb_dim)) {
+        int rc = elem_bf16 ? mli_paged_attention_encoder_bf16(emb_table, wpe, inp, reinterpret_cast<mli_bf16* const*>(page_table),
+                                                              lengths, new_item_indices, n_batch, n_sequence, emb_dim,
+                                                              n_new_items, stream)
+                           : mli_paged_attention_encoder(emb_table, wpe, inp, reinterpret_cast<float* const*>(page_table),
+                                                         lengths, new_item_indices, n_batch, n_sequence, emb_dim, n_new_items,
+                                                         stream);
+        if (rc) return rc;
+        return elem_bf16 ? mli_fill_new_k_v_cache_paged_bf16(reinterpret_cast<mli_bf16* const*>(page_table), new_item_indices,
+                                                             lengths, static_cast<const mli_bf16*>(wk),
+                                                             static_cast<const mli_bf16*>(wv), n_batch, n_sequence, emb_dim,
+                                                             n_new_items, stream)
+                         : mli_fill_new_k_v_cache_paged(reinterpret_cast<float* const*>(page_table), new_item_indices, lengths,
+                                                        static_cast<const float*>(wk), static_cast<const float*>(wv), n_batch,
+                                                        n_sequence, emb_dim, n_new_items, stream);
+    }
     if (elem_bf16)
         return mli::launch_fill_paged_bf16_embed(emb_table, wpe, inp, reinterpret_cast<mli_bf16* const*>(page_table),
                                                  new_item_indices, lengths, static_cast<const mli_bf16*>(wk),

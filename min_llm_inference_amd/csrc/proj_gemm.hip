@@ -423,6 +423,12 @@ int latest_compact(int n_batch, int k_dim) {
 static thread_local int g_deep_k_tiles = 1;  // mli_tune "gemm_deep_k" (bf16 kernel): 0 = 32-deep staged tiles everywhere
 void set_deep_k_tiles(int v) { g_deep_k_tiles = v != 0; }
 int deep_k_tiles_enabled() { return g_deep_k_tiles; }
+// mli_tune "prefill_fused": which form mli_[paged_]prefill runs: 1 (default) = the encoder as the fill GEMM's prologue up to
+// emb_dim 512 and encoder + fill as two launches beyond, 0 = always the two launches, 2 = always the prologue form
+static thread_local int g_prefill_fused = 1;
+void set_prefill_fused(int v) { g_prefill_fused = v < 0 ? 0 : (v > 2 ? 2 : v); }
+bool prefill_fuses(int emb_dim) { return g_prefill_fused == 2 || (g_prefill_fused == 1 && emb_dim <= 512); }
+
 static thread_local int g_gemm_split = 1;  // mli_tune "gemm_split": 0 = never the loader / MFMA wave split of the 64-row-tile kernel
 void set_gemm_split(int v) { g_gemm_split = v != 0; }
 static thread_local int g_gemm_tall_tiles = 1;  // mli_tune "gemm_tall_tiles": 0 = always 64-row tiles, 2 = 128-row tiles whenever allowed (tests)
@@ -671,6 +677,13 @@ int mli_prefill(const float* emb_table, const float* wpe, const int* inp, float*
                 const int* new_item_indices, const float* wk, const float* wv, float* kt_cache, float* v_cache,
                 int n_batch, int n_sequence, int input_dim, int output_dim, int n_new_items, void* stream) {
     if (emb_table == nullptr || wpe == nullptr || inp == nullptr) return MLI_ERR_BAD_ARG;
+    if (!mli::prefill_fuses(input_dim)) {   // wide models: encoder + fill as two launches (see mli_paged_prefill)
+        int rc = mli_inference_optimized_encoder(emb_table, wpe, inp, inp_embedding, lengths, new_item_indices, n_batch,
+                                                 n_sequence, input_dim, n_new_items, stream);
+        if (rc) return rc;
+        return mli_fill_new_kt_v_cache(inp_embedding, new_item_indices, lengths, wk, wv, kt_cache, v_cache, n_batch,
+                                       n_sequence, input_dim, output_dim, n_new_items, stream);
+    }
     return mli::launch_fill_naive_embed(emb_table, wpe, inp, inp_embedding, new_item_indices, lengths, wk, wv, kt_cache,
                                         v_cache, n_batch, n_sequence, input_dim, output_dim, n_new_items,
                                         mli::as_stream(stream));

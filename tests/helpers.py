@@ -180,9 +180,10 @@ def _fp8_table():
     return _FP8_TABLE
 
 
-def fp8_bits(x):
-    """float32 -> OCP e4m3fn byte codes (uint8): round to nearest, ties to the even code, SATURATING at +-448 (the
-    format has no infinity; the kernels clamp before v_cvt_pk_fp8_f32, which would give NaN from 465 on), NaN -> 0x7f."""
+def fp8_bits_by_search(x):
+    """float32 -> OCP e4m3fn byte codes (uint8), the definition spelled out: the nearest representable value, ties to the even
+    code, SATURATING at +-448 (the format has no infinity; the kernels clamp before v_cvt_pk_fp8_f32, which would give NaN from
+    465 on), NaN -> 0x7f.  Slow (float64 + a table search): kept as the model fp8_bits is checked against."""
     x = np.ascontiguousarray(x, np.float32)
     t = _fp8_table()
     a = np.minimum(np.abs(x.astype(np.float64)), 448.0)
@@ -194,12 +195,31 @@ def fp8_bits(x):
     return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
 
 
+def fp8_bits(x):
+    """The same codes by integer arithmetic on the float32 bits (what makes the fp8 tests' pools affordable): normal range --
+    round the 23-bit mantissa to 3 bits, nearest even, carry into the exponent, rebias 127 -> 7; below 2^-6 -- the subnormal
+    grid, rint(|x| * 2^9) (8 is the first normal code).  tests/test_oracle.py checks it against fp8_bits_by_search."""
+    x = np.ascontiguousarray(x, np.float32)
+    a = np.minimum(np.abs(x), np.float32(448.0))
+    u = a.view(np.uint32)
+    normal = ((u + np.uint32(0x7FFFF) + ((u >> np.uint32(20)) & np.uint32(1))) >> np.uint32(20)).astype(np.int32) - (120 << 3)
+    with np.errstate(invalid="ignore"):
+        sub = np.rint(np.nan_to_num(a) * np.float32(512.0)).astype(np.int32)
+    code = np.where(a < np.float32(2.0 ** -6), sub, normal)
+    code = np.where(np.isnan(x), 0x7f, code).astype(np.uint8)
+    return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
+
+
+_FP8_DECODE = None
+
+
 def fp8_decode(bits):
-    """OCP e4m3fn byte codes -> float32."""
-    b = np.asarray(bits, np.uint8)
-    mag = b & 0x7f
-    v = np.where(mag == 0x7f, np.nan, _fp8_table()[np.minimum(mag, 126)])
-    return np.where(b & 0x80, -v, v).astype(np.float32)
+    """OCP e4m3fn byte codes -> float32 (a 256-entry table)."""
+    global _FP8_DECODE
+    if _FP8_DECODE is None:
+        mag = np.concatenate([_fp8_table(), [np.nan]]).astype(np.float32)
+        _FP8_DECODE = np.concatenate([mag, -mag]).astype(np.float32)
+    return _FP8_DECODE[np.asarray(bits, np.uint8)]
 
 
 def fp8_round(x):

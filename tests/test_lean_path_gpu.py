@@ -500,9 +500,13 @@ def test_paged_prefill_equals_encoder_then_fill(mli, dev, seed, B, S, D, V, bf16
     args = (_t(emb, dev), _t(wpe, dev), _t(inp, dev))
     L, idx = _t(lengths, dev), _t(new_idx, dev)
     assert mli.mli_tune(b"fill_compact", compact) == 0
+    assert mli.mli_tune(b"prefill_fused", 2) == 0   # the prologue form whatever the width (the default takes two launches beyond 512)
     try:
         p1, t1 = state()
         ops.paged_prefill(*args, t1, L, idx, ws[0], ws[1], n_new)
+        mli.mli_tune(b"prefill_fused", 1)
+        p3, t3 = state()
+        ops.paged_prefill(*args, t3, L, idx, ws[0], ws[1], n_new)   # the form the entry point picks for this width
         p2, t2 = state()
         if bf16:
             ops.launch_paged_attention_encoder_kernel_bf16(*args, t2, L, idx, n_new)
@@ -513,8 +517,10 @@ def test_paged_prefill_equals_encoder_then_fill(mli, dev, seed, B, S, D, V, bf16
         torch.cuda.synchronize()
     finally:
         mli.mli_tune(b"fill_compact", 1)
+        mli.mli_tune(b"prefill_fused", 1)
     view = torch.int16 if bf16 else torch.int32
     assert torch.equal(p1.view(view), p2.view(view)), "page pool: one launch == encoder + fill"
+    assert torch.equal(p3.view(view), p2.view(view)), "page pool: the form picked by shape == encoder + fill"
     changed = (p2.view(view) != (_t(bf16_bits(pool).view(np.int16), dev) if bf16 else _t(pool, dev).view(view))).sum().item()
     assert changed > 0
 
@@ -528,7 +534,11 @@ def test_prefill_contiguous_equals_encoder_then_fill(oracle, mli, dev, seed, B, 
     args = (_t(emb, dev), _t(wpe, dev), _t(inp, dev))
     L, idx, wk, wv = _t(lengths, dev), _t(new_idx, dev), _t(w[0], dev), _t(w[1], dev)
     x1, kt1, v1 = _t(x0, dev), _t(kt0, dev), _t(v0, dev)
-    ops.prefill(*args, x1, L, idx, wk, wv, kt1, v1, n_new)
+    assert mli.mli_tune(b"prefill_fused", 2) == 0
+    try:
+        ops.prefill(*args, x1, L, idx, wk, wv, kt1, v1, n_new)
+    finally:
+        mli.mli_tune(b"prefill_fused", 1)
     x2, kt2, v2 = _t(x0, dev), _t(kt0, dev), _t(v0, dev)
     ops.launch_inference_optimized_encoder_kernel(*args, x2, L, idx, n_new)
     ops.launch_fill_new_kt_v_cache(x2, idx, L, wk, wv, kt2, v2, n_new)

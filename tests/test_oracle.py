@@ -133,3 +133,22 @@ def test_golden_vectors(oracle, name):
     for k in g.files:
         if k.startswith("out_"):
             assert_equal(out[k], g[k], f"{name}:{k}")
+
+
+def test_fp8_helper_codes_match_the_table_search_model():
+    """tests/helpers.fp8_bits (integer arithmetic on the float32 bits: what the fp8 GPU tests round their pools with) against
+    the format's definition spelled out (nearest representable value by table search, ties to the even code, saturating at 448,
+    NaN -> 0x7f): every code, every midpoint between two codes and its two float32 neighbours, the saturation edge, the subnormal
+    grid, and random values of three scales -- both signs."""
+    import helpers as h
+    rng = np.random.default_rng(5)
+    t = h._fp8_table()
+    mids = ((t[:-1] + t[1:]) / 2).astype(np.float32)
+    vals = np.concatenate([t, mids, np.nextafter(mids, np.float32(0)), np.nextafter(mids, np.float32(1e9)),
+                           [448, 449, 463.9, 464, 465, 1e9, 0, 1e-10, 2 ** -10, 2 ** -9, 2 ** -6, 2 ** -6 * 0.999],
+                           rng.standard_normal(100000) * 3, rng.random(50000) * 600, (rng.random(50000) - 0.5) * 0.05]).astype(np.float32)
+    vals = np.concatenate([vals, -vals, [np.nan]]).astype(np.float32)
+    got, want = h.fp8_bits(vals), h.fp8_bits_by_search(vals)
+    assert (got == want).all(), vals[got != want][:8]
+    assert (h.fp8_decode(np.arange(127, dtype=np.uint8)).astype(np.float64) == t).all()
+    assert np.isnan(h.fp8_decode(np.uint8(0x7f))) and h.fp8_decode(np.uint8(0xfe)) == -448
