@@ -213,8 +213,9 @@ int mli_get_latest_k_q_v_paged_lean(void* const* page_table, const int* lengths,
  * src/layers.cpp:41-56).  fill (n_new_items rows) -> latest -> ONE scan launch: a workgroup scores 256 tokens of a row
  * from the K^T tile, keeps exp(score - chunk max) in LDS, accumulates it over the V tile, and the workgroup that
  * completes a row merges its chunks (attention_fused_naive.hip).  attention_result differs from
- * mli_inference_self_attention's by fp32 rounding of the merge only.  Dims must be multiples of 4 and the caches
- * 16-byte aligned; otherwise MLI_ERR_BAD_ARG (the caller takes mli_inference_self_attention). */
+ * mli_inference_self_attention's by fp32 rounding of the merge only.  output_dim and n_sequence must be multiples of 4
+ * and the caches 16-byte aligned (the scan reads them in 16-byte pieces; input_dim is free); otherwise MLI_ERR_BAD_ARG
+ * after the projection has run (it is idempotent) and the caller takes mli_inference_self_attention. */
 int mli_self_attention_lean(const float* inp_embedding, const int* lengths,
                             const float* wk, const float* wq, const float* wv, const int* new_batch_idx,
                             float* kt_cache, float* v_cache, float* q_output, float* attention_result,
