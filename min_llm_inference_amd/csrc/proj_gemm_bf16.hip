@@ -482,8 +482,8 @@ __global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs
 //     halves of a k-row swapped when k & 2 (the 4 k-rows of a ds_read_b64_tr_b16 group land on 4 different bank
 //     quarters) -- unpadded, 40 KiB per stage, three stages: two tiles in flight while the third is multiplied;
 //   * the loaders retire a tile with a counted vmcnt (the younger tile stays in flight) and a raw s_barrier; the MFMA
-//     waves (2 x 2, 64 x 96 each: 6 accumulator tiles, 5 KiB of fragments per 6 MFMAs) read the first fragments of the
-//     next tile right behind that barrier and only then issue the last k sub-step of the previous one.
+//     waves (2 x 2, 64 x 96 each: 6 accumulator tiles, 5 KiB of fragments per 6 MFMAs) keep three fragment sets and read
+//     two k sub-steps ahead, across that barrier.
 // Same 32x32x16 MFMA steps in the same k order as the other two kernels: pages and q_output bit-identical (tested).
 constexpr int kDmThreads = 512;
 constexpr int kDmM = 128, kDmK = 64;   // (x 192 columns = three 64-column sub-tiles)
@@ -627,6 +627,7 @@ __global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, i
 #ifdef MLI_DMA_TRACE
         if (tid == 256) { MLI_DT_PUT(8, dt_wait); MLI_DT_PUT(9, dt_bar); MLI_DT_PUT(10, dt_issue); }
 #endif
+        __builtin_amdgcn_s_barrier();   // #nk: the MFMA waves' barrier in front of the last tile's (unused) look-ahead
         __builtin_amdgcn_s_barrier();   // E1: (the MFMA waves are done with the last tile)
         __builtin_amdgcn_s_barrier();   // E2: the output tile is in LDS
         asm volatile("" ::: "memory");
@@ -683,33 +684,45 @@ __global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, i
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         };
-        Frag8 fa[2][2], fb[2][3];
+        // THREE fragment sets: the reads of k sub-step s + 2 go out while sub-step s is multiplied, so a fragment has a whole
+        // sub-step (6 MFMAs) more to land than it takes the LDS under load (with two sets every sub-step began with a wait).  A
+        // tile has 4 sub-steps, so set and stage indices repeat every 3 tiles: the loop body is 3 tiles with everything static.
+        // Barrier #(t + 1) sits in front of sub-step 2 of tile t, whose look-ahead is the next tile's first fragments; every read
+        // of tile t has been issued (and is waited for by the barrier's fence) by then, so the loaders may refill its stage.
+        Frag8 fa[3][2], fb[3][3];
         __syncthreads();  // #0
         MLI_DT(dt_first);
 #ifdef MLI_DMA_TRACE
         unsigned long long dt_mbar = 0;
 #endif
         read_frags(dm_smem, 0, fa[0], fb[0]);
-        for (int t = 0; t < nk; ++t) {
-            const unsigned char* st = dm_smem + (t % kDmStages) * kDmStageBytes;
-            read_frags(st, 1, fa[1], fb[1]);
-            multiply(fa[0], fb[0]);
-            interleave();
-            read_frags(st, 2, fa[0], fb[0]);
-            multiply(fa[1], fb[1]);
-            interleave();
-            read_frags(st, 3, fa[1], fb[1]);
-            multiply(fa[0], fb[0]);
-            interleave();
-            if (t + 1 < nk) {
-                MLI_DT(m0t);
-                __syncthreads();  // #(t + 1): every read of tile t is complete (the fence waits for them)
+        read_frags(dm_smem, 1, fa[1], fb[1]);
+        for (int t0 = 0; t0 < nk; t0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = t0 + j;
+                if (t < nk) {   // (workgroup-uniform)
+                    const unsigned char* st = dm_smem + j * kDmStageBytes;               // t % 3 == j
+                    const unsigned char* nx = dm_smem + ((j + 1) % 3) * kDmStageBytes;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cur = (4 * j + q) % 3, ahead = (4 * j + q + 2) % 3;
+                        if (q == 2) {
+                            MLI_DT(m0t);
+                            __syncthreads();  // #(t + 1)
 #ifdef MLI_DMA_TRACE
-                dt_mbar += clock64() - m0t;
+                            dt_mbar += clock64() - m0t;
 #endif
-                read_frags(dm_smem + ((t + 1) % kDmStages) * kDmStageBytes, 0, fa[0], fb[0]);
+                        }
+                        // (no condition on the last tile: its look-ahead reads a stage nobody writes any more and is never
+                        // multiplied -- a branch here would end the basic block, and with it the interleaving and hipcc's
+                        // exact lgkmcnt bookkeeping, in every tile)
+                        read_frags(q < 2 ? st : nx, (q + 2) & 3, fa[ahead], fb[ahead]);
+                        multiply(fa[cur], fb[cur]);
+                        interleave();
+                    }
+                }
             }
-            multiply(fa[1], fb[1]);
         }
         MLI_DT(dt_loop_end);
 #ifdef MLI_DMA_TRACE
