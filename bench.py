@@ -412,8 +412,10 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
     run the counter passes on itself, so this is null when no summary for the workload is committed."""
     path = os.path.join(ROOT, "profiles", f"pmc_{workload}{'' if dtype == 'f32' else '_' + dtype}.json")
     if not os.path.exists(path):
-        return None, None
-    kernels = json.load(open(path))["kernels"]
+        return None, None, None
+    summary = json.load(open(path))
+    kernels = summary["kernels"]
+    run_bytes = (summary.get("counter_run") or {}).get("algorithmic_bytes_per_launch") if which == "scan_lean" else None
     needle = {"qkt": "qkt_", "softmax_v": "softmax_v_partial", "scan": "fused_decode_scan", "scan_lean": "fused_decode_s"}[which]
     # the chunked scan kernel's template arguments end in "..., SCORES, RPI>": SCORES says whether it writes the raw scores
     # (the materialising form); the equal-shares kernel (fused_decode_stream_kernel) exists in the lean form only
@@ -431,7 +433,7 @@ def pmc_traffic(workload, which, layout, dtype="f32"):
         hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k and scores_flag(k) == "true"]
     else:
         hits = [v["traffic_bytes"] for k, v in kernels.items() if needle in k]
-    return (hits[0], os.path.relpath(path, ROOT)) if hits else (None, None)
+    return (hits[0], os.path.relpath(path, ROOT), run_bytes) if hits else (None, None, None)
 
 
 def run_engine_mode(args, rank, world, dev):
@@ -737,10 +739,13 @@ def roofline_report(wl, workload, dtype, lengths_now, ms_per_step, reps, lean=Tr
     dom = max(key_of, key=lambda k: times[key_of[k]])
     ms = times[key_of[dom]]
     achieved = alg[dom] / (ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(workload, dom, wl.layout, dtype)
+    traffic, traffic_src, traffic_run_bytes = pmc_traffic(workload, dom, wl.layout, dtype)
     return {
         "bound": "hbm", "kernel": key_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        # the counter passes ran fewer steps than this run (shorter rows): their own algorithmic bytes, so that the ratio
+        # compares like with like (1.0 = no re-reads)
+        "traffic_over_algorithmic_of_counter_run": (traffic / traffic_run_bytes) if traffic and traffic_run_bytes else None,
         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms, "kernel_ms": times,
         "sum_of_launches_ms": sum(times.values()),
         "step_algorithmic_bytes": alg["step"],

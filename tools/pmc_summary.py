@@ -2,7 +2,10 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_summary.py c4 gpurun_out/pmc_fetch gpurun_out/pmc_write
+    python tools/pmc_summary.py c4 gpurun_out/pmc_fetch gpurun_out/pmc_write [bench line of the counter run]
+
+With the counter run's own bench line (its lengths differ from a default run's: fewer steps), the summary also records the
+ALGORITHMIC bytes per launch of the dominant kernel in that run, so that traffic / algorithmic compares like with like.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: the counters are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (128-B requests
@@ -28,6 +31,7 @@ def per_kernel(directory, counter):
 
 def main():
     workload, fetch_dir, write_dir = sys.argv[1:4]
+    line = sys.argv[4] if len(sys.argv) > 4 else None
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
     out = {"workload": workload, "unit": "bytes per launch",
@@ -39,6 +43,13 @@ def main():
         out["kernels"][k] = {"fetch_size_kib_raw": f_kib, "write_size_kib_raw": w_kib, "launches": max(nf, nw),
                              "read_bytes": 2 * f_kib * 1024, "write_bytes": w_kib * 1024,
                              "traffic_bytes": 2 * f_kib * 1024 + w_kib * 1024}
+    if line and os.path.exists(line):
+        rows = [ln for ln in open(line) if ln.startswith("{")]
+        if rows:
+            roof = json.loads(rows[-1]).get("roofline", {})
+            out["counter_run"] = {"dominant_kernel": roof.get("kernel"),
+                                  "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
+                                  "note": "the dominant (lean scan) kernel's algorithmic bytes at the lengths of the counter run"}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"pmc_{workload}.json")
     json.dump(out, open(path, "w"), indent=1)
     for k, v in out["kernels"].items():

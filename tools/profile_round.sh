@@ -18,7 +18,7 @@ run_stats() {  # name, bench args...
 }
 run_pmc() {    # name, counter, bench args...
     local name=$1 counter=$2; shift 2
-    rocprofv3 --kernel-trace --pmc "$counter" --output-format csv -d "$OUT/pmc_${counter}_$name" -- python3 "$B" "$@" > /dev/null 2> "$OUT/pmc_${counter}_$name.err" || echo "pmc $counter $name failed"
+    rocprofv3 --kernel-trace --pmc "$counter" --output-format csv -d "$OUT/pmc_${counter}_$name" -- python3 "$B" "$@" > "$OUT/pmc_${counter}_$name.json" 2> "$OUT/pmc_${counter}_$name.err" || echo "pmc $counter $name failed"
     echo "pmc $counter $name done"
 }
 run_stats c4_bf16 --no-configs --no-cpu-baseline
