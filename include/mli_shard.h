@@ -39,6 +39,14 @@ typedef struct {
 int mli_shard_group_create(const mli_engine_config* config, int n_ranks, const int* devices, const float* emb_table,
                            const float* pos_table, const float* wk, const float* wq, const float* wv,
                            mli_shard_group** out);
+/* The same group over a LOOPBACK exchange: every rank's engine lives on ONE device (`device`), and the all-gather is n_ranks
+ * device-to-device copies per rank on the engine's stream instead of a collective (RCCL refuses a communicator with one GPU
+ * twice).  For hosts that run several engine replicas on one GPU (each replica's host bookkeeping overlaps the others' kernels)
+ * -- and it is how the lock-step logic (ranks that finish early, empty ranks, failures) is tested on a one-GPU box.  Everything
+ * else (item dealing, stepping, stats, mli_shard_group_gathered) is identical; stats.ranks_seen = n_ranks by construction. */
+int mli_shard_group_create_loopback(const mli_engine_config* config, int n_ranks, int device, const float* emb_table,
+                                    const float* pos_table, const float* wk, const float* wq, const float* wv,
+                                    mli_shard_group** out);
 void mli_shard_group_destroy(mli_shard_group* group);
 
 int mli_shard_group_size(const mli_shard_group* group);

@@ -121,6 +121,7 @@ ENGINE_SIGNATURES = {
     "mli_engine_stream": [_P, _PP],
     # include/mli_shard.h: the row-sharded engine group (one engine per GPU, RCCL all-gather of the token ids)
     "mli_shard_group_create": [ctypes.POINTER(EngineConfig), _I, _P, _P, _P, _P, _P, _P, _PP],
+    "mli_shard_group_create_loopback": [ctypes.POINTER(EngineConfig), _I, _I, _P, _P, _P, _P, _P, _PP],
     "mli_shard_group_destroy": [_P],
     "mli_shard_group_size": [_P],
     "mli_shard_group_add_item": [_P, _I, _P, _I],

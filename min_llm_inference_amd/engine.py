@@ -109,13 +109,20 @@ class ShardGroup:
     all-gather of the generated token ids per rank and iteration.  `n_batch` / `n_blocks` are PER RANK."""
 
     def __init__(self, kind, n_batch, n_sequence, emb_dim, n_vocab, emb_table, pos_table, wk, wq, wv, devices, n_blocks=0,
-                 n_forward_rounds=1):
+                 n_forward_rounds=1, loopback_ranks=0):
+        """devices: one ordinal per rank (RCCL communicator); or loopback_ranks = N: N ranks on devices[0], exchange by
+        device-to-device copies (mli_shard_group_create_loopback)."""
         self._lib = load_library()
         self.devices = [int(d) for d in devices]
         self.cfg = EngineConfig(kind, n_batch, n_sequence, emb_dim, n_vocab, n_blocks, n_forward_rounds, 0, 0)
         keep = [_fp(x) for x in (emb_table, pos_table, wk, wq, wv)]
         dev = np.asarray(self.devices, dtype=np.int32)
         self._h = ctypes.c_void_p()
+        if loopback_ranks:
+            self._check(self._lib.mli_shard_group_create_loopback(ctypes.byref(self.cfg), int(loopback_ranks), self.devices[0],
+                                                                  *[k[1] for k in keep], ctypes.byref(self._h)))
+            self.devices = [self.devices[0]] * int(loopback_ranks)
+            return
         self._check(self._lib.mli_shard_group_create(ctypes.byref(self.cfg), len(self.devices),
                                                      dev.ctypes.data_as(ctypes.c_void_p), *[k[1] for k in keep],
                                                      ctypes.byref(self._h)))

@@ -113,10 +113,11 @@ struct mli_shard_group {
     int count = 0;                 // token ids per rank and iteration
     int ranks_seen = 0;
     bool ran = false;
+    bool loopback = false;         // every rank on one device; the exchange is device-to-device copies, no communicator
 
     ~mli_shard_group() {
         for (int r = 0; r < (int)comms.size(); ++r)
-            if (comms[r]) {
+            if (comms[r] && !loopback) {
                 (void)hipSetDevice(devices[r]);
                 rccl().comm_destroy(comms[r]);
             }
@@ -145,15 +146,14 @@ extern "C" {
 
 const char* mli_shard_last_error(void) { return g_shard_error.c_str(); }
 
-int mli_shard_group_create(const mli_engine_config* config, int n_ranks, const int* devices, const float* emb_table,
-                           const float* pos_table, const float* wk, const float* wq, const float* wv,
-                           mli_shard_group** out) {
-    if (!config || !devices || !out || n_ranks < 1 || n_ranks > 64) { g_shard_error = "bad argument"; return -1; }
-    for (int a = 0; a < n_ranks; ++a)
-        for (int b = a + 1; b < n_ranks; ++b)
-            if (devices[a] == devices[b]) { g_shard_error = "one rank per device: duplicate device ordinal"; return -1; }
-    SHARD_GUARD({
-        const Rccl& api = rccl();
+}  // extern "C"
+
+namespace {
+
+// the engines, their private streams and the gathered buffers of a group (no exchange yet)
+std::unique_ptr<mli_shard_group> make_group(const mli_engine_config* config, int n_ranks, const int* devices,
+                                            const float* emb_table, const float* pos_table, const float* wk, const float* wq,
+                                            const float* wv) {
         auto group = std::unique_ptr<mli_shard_group>(new mli_shard_group());
         group->n = n_ranks;
         group->devices.assign(devices, devices + n_ranks);
@@ -179,6 +179,36 @@ int mli_shard_group_create(const mli_engine_config* config, int n_ranks, const i
             hip_ok(hipMalloc(&group->gathered[r], (size_t)n_ranks * count * sizeof(int)), "hipMalloc(gathered)");
             hip_ok(hipMemset(group->gathered[r], 0, (size_t)n_ranks * count * sizeof(int)), "hipMemset(gathered)");
         }
+        return group;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mli_shard_group_create_loopback(const mli_engine_config* config, int n_ranks, int device, const float* emb_table,
+                                    const float* pos_table, const float* wk, const float* wq, const float* wv,
+                                    mli_shard_group** out) {
+    if (!config || !out || n_ranks < 1 || n_ranks > 64) { g_shard_error = "bad argument"; return -1; }
+    SHARD_GUARD({
+        const std::vector<int> devices(n_ranks, device);
+        auto group = make_group(config, n_ranks, devices.data(), emb_table, pos_table, wk, wq, wv);
+        group->loopback = true;
+        group->ranks_seen = n_ranks;
+        *out = group.release();
+    })
+}
+
+int mli_shard_group_create(const mli_engine_config* config, int n_ranks, const int* devices, const float* emb_table,
+                           const float* pos_table, const float* wk, const float* wq, const float* wv,
+                           mli_shard_group** out) {
+    if (!config || !devices || !out || n_ranks < 1 || n_ranks > 64) { g_shard_error = "bad argument"; return -1; }
+    for (int a = 0; a < n_ranks; ++a)
+        for (int b = a + 1; b < n_ranks; ++b)
+            if (devices[a] == devices[b]) { g_shard_error = "one rank per device: duplicate device ordinal"; return -1; }
+    SHARD_GUARD({
+        const Rccl& api = rccl();
+        auto group = make_group(config, n_ranks, devices, emb_table, pos_table, wk, wq, wv);
         nccl_ok(api.comm_init_all(group->comms.data(), n_ranks, group->devices.data()), "ncclCommInitAll");
         // self-proof that the communicator spans n_ranks: all-reduce of ones (grouped: one thread drives every rank here)
         std::vector<int*> ones(n_ranks, nullptr);
@@ -225,7 +255,7 @@ int mli_shard_group_run(mli_shard_group* group, mli_shard_stats* stats) {
     SHARD_GUARD({
         if (group->ran) throw std::runtime_error("a shard group runs once");
         group->ran = true;
-        const Rccl& api = rccl();
+        const Rccl* api = group->loopback ? nullptr : &rccl();
         const int n = group->n;
         StepBarrier barrier(n);
         std::vector<std::string> errors(n);
@@ -257,14 +287,26 @@ int mli_shard_group_run(mli_shard_group* group, mli_shard_stats* stats) {
                 }
                 if (barrier.arrive(failed.load())) break;   // somebody failed before the collective of this round
                 const auto g0 = std::chrono::steady_clock::now();
-                const ncclResult_t rc = api.all_gather(result, group->gathered[r], (size_t)count, ncclInt32, group->comms[r],
-                                                       static_cast<hipStream_t>(group->streams[r]));
+                if (api) {
+                    const ncclResult_t rc = api->all_gather(result, group->gathered[r], (size_t)count, ncclInt32, group->comms[r],
+                                                            static_cast<hipStream_t>(group->streams[r]));
+                    if (rc != ncclSuccess) {
+                        errors[r] = std::string("ncclAllGather: ") + api->error_string(rc);
+                        failed.store(true);
+                    }
+                } else {   // loopback: this rank's slice into every rank's buffer, behind the forward on this rank's stream
+                    for (int q = 0; q < n && errors[r].empty(); ++q) {
+                        const hipError_t e = hipMemcpyAsync(static_cast<int*>(group->gathered[q]) + (size_t)r * count, result,
+                                                            (size_t)count * sizeof(int), hipMemcpyDeviceToDevice,
+                                                            static_cast<hipStream_t>(group->streams[r]));
+                        if (e != hipSuccess) {
+                            errors[r] = std::string("loopback gather: ") + hipGetErrorString(e);
+                            failed.store(true);
+                        }
+                    }
+                }
                 gather_seconds[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
                 ++iterations[r];
-                if (rc != ncclSuccess) {
-                    errors[r] = std::string("ncclAllGather: ") + api.error_string(rc);
-                    failed.store(true);
-                }
                 if (!barrier.arrive(!done || failed.load())) break;   // nobody has work left
                 if (failed.load()) break;
             }

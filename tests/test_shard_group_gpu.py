@@ -71,3 +71,45 @@ def test_duplicate_devices_and_bad_arguments_are_refused(mli, dev):
     with pytest.raises(MliError):
         eng.ShardGroup(eng.PAGED, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
                        devices=[], n_blocks=4 * B)
+
+
+@pytest.mark.parametrize("n_ranks,n_items", [(2, 90), (3, 40), (4, 2)])
+def test_loopback_group_runs_ranks_in_lock_step(mli, dev, n_ranks, n_items):
+    """N ranks on the one GPU of the test box (mli_shard_group_create_loopback: the exchange is device-to-device copies, everything
+    else -- item dealing, one host thread per rank, the lock-step barrier, ranks that run out of work early or never had any
+    (4 ranks, 2 items) -- is the code of the RCCL group).  Every item's tokens equal the single engine's; the gathered buffer of
+    every rank holds every rank's last decoder output."""
+    import torch
+    from min_llm_inference_amd import engine as eng
+    B, S, D, V = 16, 128, 128, 1024
+    model = make_model(94, V, S, D)
+    items = make_items(95, n_items, 1, 50)
+    want = _single(eng.PAGED_GEMM, model, items, B * n_ranks, S, 4 * B * n_ranks)
+    g = eng.ShardGroup(eng.PAGED_GEMM, B, S, D, V, model["emb_table"], model["pos_table"], model["wk"], model["wq"], model["wv"],
+                       devices=[0], n_blocks=4 * B, loopback_ranks=n_ranks)
+    for item_id, toks in items:
+        g.add_item(item_id, toks)
+    st = g.run()
+    assert st.ranks_seen == n_ranks and st.finished == len(items)
+    got = {}
+    for r in range(n_ranks):
+        mine = {i: t for i, t in g.engine(r).finished()}
+        assert all(i % n_ranks == r for i in mine), "items are dealt to rank id % n_ranks"
+        got.update(mine)
+    assert st.total_tokens == sum(len(got[i]) - len(t) for i, t in items)
+    for item_id, _ in items:
+        assert len(got[item_id]) == len(want[item_id]) and (got[item_id] == want[item_id]).all(), item_id
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    results = np.empty((n_ranks, B), np.int32)
+    for r in range(n_ranks):
+        rp, rn = g.engine(r).decoder_result_ptr()
+        assert rn == B and hip.hipMemcpy(results[r].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(rp), B * 4, 2) == 0
+    for r in range(n_ranks):
+        gp, gn = g.gathered_ptr(r)
+        assert gn == n_ranks * B
+        buf = np.empty((n_ranks, B), np.int32)
+        assert hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(gp), n_ranks * B * 4, 2) == 0
+        # a rank that stopped stepping keeps its last output; the copies of the last common iteration carry it everywhere
+        assert (buf == results).all(), f"gathered buffer of rank {r}"
+    g.close()
