@@ -1,4 +1,5 @@
-"""bf16 decode projection at B=1024, D=2048: the tiled kernel against the loader / MFMA wave split (tuning aid)."""
+"""bf16 decode projection at B=1024, D=2048: the tiled kernel (split0) against the register-staging loader / MFMA wave split
+(split1) and the LDS-DMA loader kernel (split2), timed in one process; checks that pages and q_output are bit-identical."""
 import sys, os, json, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

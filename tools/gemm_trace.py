@@ -20,16 +20,13 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(50): fn()
 torch.cuda.synchronize(); us_per_launch = (time.perf_counter() - t0) / 50 * 1e6
 fn(); torch.cuda.synchronize()
-buf = np.zeros((1024, 8), np.uint64); end = np.zeros(1024, np.uint64)
-assert raw.mli_debug_gemm_trace(buf.ctypes.data_as(ctypes.c_void_p), end.ctypes.data_as(ctypes.c_void_p), 1024) == 0
-m = buf[:, 5] > 0
-t = buf[m].astype(np.float64); e = end[m].astype(np.float64)
-span = e.max() - t[:, 7].min()
-print(f"{len(t)} workgroups traced; kernel span {span:.0f} ticks for ~{us_per_launch:.1f} us per launch (host clock, back to back) -> {span / us_per_launch / 1e3:.2f} ticks per ns")
+buf = np.zeros((1024, 8), np.uint64)
+assert raw.mli_debug_gemm_trace(buf.ctypes.data_as(ctypes.c_void_p), 1024) == 0
+# per workgroup: [0..4] clocks in the five phases of the k loop (thread 0), [5] the k loop, [6] its start stamp, [7] k steps
+t = buf[buf[:, 5] > 0].astype(np.float64)
+print(f"{len(t)} workgroups traced; ~{us_per_launch:.1f} us per launch (host clock, back to back)")
 names = ["issue next tile's loads", "fragment reads + MFMAs", "barrier 1", "wait for the loads + store to LDS", "barrier 2"]
 tot = t[:, 5]
 for i, n in enumerate(names):
     print(f"  {n:36s} {100 * t[:, i].mean() / tot.mean():5.1f} % of the k loop")
-life = e - t[:, 7]
-print(f"  per workgroup: entry -> k loop {np.mean(t[:, 6] - t[:, 7]):.0f} ticks, k loop {tot.mean():.0f}, k loop end -> last store landed {np.mean(e - t[:, 6] - tot):.0f}; lifetime {life.mean():.0f} = {100 * life.mean() / span:.0f} % of the span")
-print(f"  workgroup entries (ticks after the first): p0 {0:.0f} p50 {np.median(t[:, 7] - t[:, 7].min()):.0f} p100 {(t[:, 7] - t[:, 7].min()).max():.0f}")
+print(f"  k loop: {tot.mean():.0f} clocks = {np.mean(tot / np.maximum(t[:, 7], 1)):.0f} per k step of the staged tile")
