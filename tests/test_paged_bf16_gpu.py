@@ -177,3 +177,37 @@ def test_bf16_latest_loader_mfma_wave_split_equals_the_tiled_kernel(oracle, mli,
     oracle.get_latest_kt_q_v(c["inp_embedding"], c["lengths"], c["wk"], c["wq"], c["wv"], c["kt_cache"], c["v_cache"],
                              c["q_output"])
     assert_close(got[0][1], c["q_output"], thr=2e-4, what="q_output vs oracle")
+
+
+@pytest.mark.parametrize("B,S,D", [(1024, 16, 2048), (300, 16, 1088)])
+def test_bf16_lds_dma_projection_is_stable_over_many_launches_under_load(oracle, mli, dev, B, S, D):
+    """Race screen of the LDS-DMA projection kernel (counted vmcnt, raw barriers, stages re-used two tiles later): 60 launches
+    while a second stream streams 512 MiB through the chip (DMA landings arrive late and out of step), every one bit-identical to
+    the tiled kernel's pages and q_output.  tools/gemm_bf16_race_screen.py runs the long form (profiles/r03_gemm_bf16_race_screen.json)."""
+    from min_llm_inference_amd import ops
+    c, d = _case(oracle, dev, 75, B, S, D, zero_every=6)
+    pool0 = d["pool"].clone()
+    side = torch.cuda.Stream(device=dev)
+    big, sink = torch.empty(1 << 27, device=dev).uniform_(), torch.zeros(64, device=dev)
+
+    def run(split):
+        assert mli.mli_tune(b"gemm_bf16_split", split) == 0
+        d["pool"].copy_(pool0)
+        d["q_output"].fill_(3.0)
+        ops.launch_get_latest_k_q_v_paged_attention_bf16(d["page_table"], d["lengths"], d["wk"], d["wq"], d["wv"], d["q_output"], S)
+        return d["pool"].clone(), d["q_output"].clone()
+
+    try:
+        assert mli.mli_tune(b"gemm_tall_tiles", 2) == 0
+        p_ref, q_ref = run(0)
+        for i in range(60):
+            if i % 4 == 0:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ops.stream_read(big, sink)
+            p, q = run(2)
+            assert torch.equal(p, p_ref) and torch.equal(q, q_ref), f"launch {i} differs from the tiled kernel"
+    finally:
+        mli.mli_tune(b"gemm_tall_tiles", 1)
+        mli.mli_tune(b"gemm_bf16_split", 2)
+        torch.cuda.synchronize()
