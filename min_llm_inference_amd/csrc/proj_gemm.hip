@@ -19,8 +19,7 @@
 
 namespace mli {
 
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LDA = BM + 1;   // k-major LDS tiles written transposed with b32 stores: +1 is conflict-free
+constexpr int BM = 64, BN = 64;   // (rows per workgroup and the k extent of a staged tile are set inside the kernel)
 constexpr int LDB = BN + 4;   // [k][n] tile written with b128 stores: rows stay 16-byte aligned
 constexpr int LDBT = BN + 1;  // [n][k] source (transposed B): same treatment as A
 constexpr int kGemmThreads = 256;
@@ -296,8 +295,9 @@ __global__ __launch_bounds__(SPLIT ? 2 * kGemmThreads : kGemmThreads) void gemm_
         // One wave doing everything in turn (issue loads, wait, write LDS, read fragments, multiply) is overlapped only by
         // the other waves of its SIMD; with about one workgroup per CU (logits of 1024 rows, prefill of a few hundred
         // tokens: 256 tiles of 64 x 64) nothing overlaps and the matrix pipe idles half the time.  Here four waves only load
-        // (two tiles in flight in their registers) and four only multiply, one barrier per k step -- the structure of
-        // gemm_bf16_split_kernel.  Same MFMA chain per output element: bit-identical results.
+        // (two tiles in flight in their registers) and four only multiply, one barrier per k step -- the structure round 2
+        // found on the bf16 projection (whose loaders have since become LDS-DMA issuers, proj_gemm_bf16.hip).  Same MFMA
+        // chain per output element: bit-identical results.
         float* As1 = As + BK * LDA;
         float* Bs1 = Bs + BK * LDBX;
         if (is_loader) {

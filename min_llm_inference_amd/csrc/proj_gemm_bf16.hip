@@ -20,7 +20,7 @@
 
 namespace mli {
 
-constexpr int HM = 64, HN = 64, HK = 32;
+constexpr int HM = 64, HN = 64;   // (the k extent of a staged tile is the kernel's KB parameter)
 constexpr int kLdbBytes = HN * 2 + 64;   // 192
 constexpr int kHThreads = 256;
 
@@ -267,211 +267,16 @@ __global__ __launch_bounds__(kHThreads) void gemm_bf16_mfma_kernel(GemmArgs g) {
     }
 }
 
-// ---- the large decode projection (B >= 1024 rows at emb_dim >= 1024): loader waves and MFMA waves -------------------
+// ---- the large decode projection (>= 1024 rows at emb_dim >= 1024): LDS-DMA loader waves + MFMA waves ------------------
 // In the kernel above one wave does everything in turn -- issue the next tile's global loads (the issue itself takes the
-// time the CU's vector-memory path needs for the bytes), wait for them, write them to LDS, read fragments, multiply --
-// and only other waves of the SIMD overlap any of it: cycle stamps (-DMLI_GEMM_TRACE) put 25 % of the k loop into load
-// issue, 24 % into waiting + LDS writes, 27 % into fragment reads + MFMAs, and neither a 128 x 128 tile nor two or three
-// tiles in flight in registers change the total (47-50 us at B=1024, D=2048 for all of them).  Here a 512-thread workgroup splits the two jobs: waves 4-7 only move the next 128 x 64 A tile
-// and 64 x 128 B tile from global memory into the other LDS buffer (two tiles in flight in their registers: they hold no
-// accumulators), waves 0-3 (2 x 2, 64 x 64 each) only read fragments and multiply; one barrier per k step.
-constexpr int kSplitThreads = 512;
-constexpr int kSpM = 128, kSpN = 128, kSpK = 64;
-constexpr int kSpLdaBytes = kSpK * 2 + 16;    // 144
-constexpr int kSpLdbBytes = kSpN * 2 + 64;    // 320
-constexpr int kSpABytes = kSpM * kSpLdaBytes;  // 18432
-constexpr int kSpBBytes = kSpK * kSpLdbBytes;  // 20480
-constexpr size_t kSplitSmem = 2 * (size_t)(kSpABytes + kSpBBytes) + 2 * kSpM * sizeof(void*);
-static_assert(sizeof(FillIndex) <= 2 * (kSpABytes + kSpBBytes), "the row index is built in the tile buffers");
-
-template <int MODE>
-__global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs g) {
-    static_assert(MODE == kPagedLatest, "decode projection only");
-    extern __shared__ __align__(16) unsigned char sp_smem[];
-    unsigned char* As = sp_smem;                                  // [2][kSpABytes]
-    unsigned char* Bs = sp_smem + 2 * kSpABytes;                  // [2][kSpBBytes]
-    const float** a_ptr = reinterpret_cast<const float**>(sp_smem + 2 * (kSpABytes + kSpBBytes));  // [kSpM]
-    float** o_ptr = (float**)(a_ptr + kSpM);                                       // [kSpM]
-    FillIndex& fill_index = *reinterpret_cast<FillIndex*>(sp_smem);  // prologue only, then the tiles take the space
-
-    const int tiles_n = g.N / kSpN;
-    const int wsel = blockIdx.x / tiles_n;
-    const int n0 = (blockIdx.x % tiles_n) * kSpN;
-    const int m0 = blockIdx.y * kSpM;
-    const int out_id = g.out_id[wsel];
-    const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.w[wsel]);
-    const int tid = threadIdx.x;
-
-    int fill_total = 0;
-    if (g.compact) {
-        fill_total = build_fill_index<kSplitThreads, true>(g, fill_index);
-        if (m0 >= fill_total) return;  // workgroup-uniform
-    }
-    if (tid < kSpM) {
-        RowDesc r{nullptr, nullptr, nullptr, nullptr};
-        if (g.compact) {
-            if (m0 + tid < fill_total) {
-                int zz, ss;
-                fill_index_lookup(fill_index, g.B, m0 + tid, zz, ss);
-                r = resolve_row<MODE, true>(g, zz, 0, out_id);
-            }
-        } else {
-            r = resolve_row<MODE, true>(g, m0 + tid, 0, out_id);
-        }
-        a_ptr[tid] = r.a;
-        o_ptr[tid] = r.o;
-    }
-    __syncthreads();  // (also: nobody reads the row index any more)
-
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nk = g.K / kSpK;
-
-    if (wave >= 4) {
-        // ---------------- loader waves ----------------
-        const int lt = tid - 256;
-        constexpr int AP = kSpM * kSpK / (256 * 8);   // 4 x 16-byte A loads per thread and tile
-        constexpr int BP = kSpK * kSpN / (256 * 8);   // 4 x 16-byte B loads
-        const int a_row = lt >> 3, a_k8 = (lt & 7) * 8;      // 32 rows per pass
-        const int b_row = lt >> 4, b_n8 = (lt & 15) * 8;     // 16 k-rows per pass
-        const uint16_t* a_src[AP];
-#pragma unroll
-        for (int p = 0; p < AP; ++p) a_src[p] = reinterpret_cast<const uint16_t*>(a_ptr[a_row + p * 32]);
-        constexpr int PDL = 2;  // tiles in flight in the loaders' registers (a third set costs the second workgroup per CU)
-        uint4 ra[PDL][AP], rb[PDL][BP];
-        auto load_tile = [&](int t, uint4 (&a_reg)[AP], uint4 (&b_reg)[BP]) {
-            const int k0 = t * kSpK;
-#pragma unroll
-            for (int p = 0; p < AP; ++p)
-                a_reg[p] = (t < nk && a_src[p] != nullptr) ? *reinterpret_cast<const uint4*>(a_src[p] + k0 + a_k8) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int p = 0; p < BP; ++p)
-                b_reg[p] = t < nk ? *reinterpret_cast<const uint4*>(W + (int64_t)(k0 + b_row + p * 16) * g.N + n0 + b_n8) : make_uint4(0, 0, 0, 0);
-        };
-        auto store_tile = [&](int buf, const uint4 (&a_reg)[AP], const uint4 (&b_reg)[BP]) {
-            unsigned char* A = As + buf * kSpABytes;
-            unsigned char* B = Bs + buf * kSpBBytes;
-#pragma unroll
-            for (int p = 0; p < AP; ++p) *reinterpret_cast<uint4*>(&A[(a_row + p * 32) * kSpLdaBytes + a_k8 * 2]) = a_reg[p];
-#pragma unroll
-            for (int p = 0; p < BP; ++p) *reinterpret_cast<uint4*>(&B[(b_row + p * 16) * kSpLdbBytes + b_n8 * 2]) = b_reg[p];
-        };
-        // register set (t % PDL) holds tile t.  Tile 0 goes to buffer 0 before the first barrier; during step t (the MFMA
-        // waves multiply buffer t & 1) tile t + 1 goes from its registers to buffer (t + 1) & 1 and tile t + 1 + PDL is
-        // requested into the registers that held it
-#pragma unroll
-        for (int i = 0; i < PDL; ++i) load_tile(i, ra[i], rb[i]);
-        store_tile(0, ra[0], rb[0]);
-        load_tile(PDL, ra[0], rb[0]);
-        __syncthreads();  // tile 0 is in buffer 0
-        for (int t0 = 0; t0 < nk; t0 += 2 * PDL) {   // 2 * PDL steps per trip: register set and LDS buffer are both static
-#pragma unroll
-            for (int i = 0; i < 2 * PDL; ++i) {
-                const int t = t0 + i;
-                if (t < nk) {  // workgroup-uniform
-                    const int set = (i + 1) % PDL;  // (constants once the slot loop is unrolled)
-                    if (t + 1 < nk) store_tile((i + 1) & 1, ra[set], rb[set]);
-                    load_tile(t + 1 + PDL, ra[set], rb[set]);
-                    __syncthreads();
-                }
-            }
-        }
-        return;
-    }
-
-    // ---------------- MFMA waves: 2 x 2, 64 x 64 each ----------------
-    const int wm = (wave >> 1) * 64;
-    const int wn = (wave & 1) * 64;
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-    const int li = lane & 31, lh = lane >> 5;
-    const unsigned a_off = (unsigned)((wm + li) * kSpLdaBytes + lh * 16);
-    const int grp_col = wn + 16 * ((lane >> 4) & 1);
-    const int tq = (lane >> 2) & 3, tp = lane & 3;
-    const unsigned b_off = (unsigned)((8 * lh + tq) * kSpLdbBytes + (grp_col + 4 * tp) * 2);
-    // fragments of k sub-step kk + 16 are requested before the MFMAs of kk are issued: the matrix pipe never waits for an
-    // LDS round trip inside a tile (one exposed round trip per tile, at its start)
-    auto read_frags = [&](const unsigned char* A, const unsigned char* B, int kk, Frag8 (&a)[2], Frag8 (&b)[2]) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            b[nt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&B[b_off + nt * 64 + kk * kSpLdbBytes]));
-            b[nt].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&B[b_off + nt * 64 + (kk + 4) * kSpLdbBytes]));
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a[mt].u = *reinterpret_cast<const uint4*>(&A[a_off + mt * 32 * kSpLdaBytes + kk * 2]);
-    };
-    auto multiply = [&](int buf) {
-        const unsigned char* A = As + buf * kSpABytes;
-        const unsigned char* B = Bs + buf * kSpBBytes;
-        Frag8 fa[2][2], fb[2][2];
-        read_frags(A, B, 0, fa[0], fb[0]);
-#pragma unroll
-        for (int q = 0; q < kSpK / 16; ++q) {
-            if (q + 1 < kSpK / 16) read_frags(A, B, (q + 1) * 16, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q & 1][mt].v, fb[q & 1][nt].v, acc[mt][nt], 0, 0, 0);
-        }
-    };
-    __syncthreads();  // tile 0 is in buffer 0
-    for (int t = 0; t < nk; t += 2) {
-        multiply(0);
-        __syncthreads();
-        if (t + 1 < nk) {
-            multiply(1);
-            __syncthreads();
-        }
-    }
-    // epilogue: register r of lane l is (row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31)
-    if (out_id == 1) {  // q: fp32, 128 contiguous bytes per row and store instruction
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* op = o_ptr[wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-                    if (op != nullptr) op[n0 + wn + nt * 32 + li] = acc[mt][nt][r];
-                }
-        return;
-    }
-    // K / V: bf16 page rows.  Straight from the accumulators a store instruction writes 2 x 64 bytes (a lane holds ONE
-    // column); through LDS (the tile buffers are free: the loop's last barrier is behind every wave) a lane gets 8
-    // consecutive columns of a row: 16-byte stores, 8 instead of 64 per wave
-    constexpr int kTPitch = 64 * 2 + 16;
-    unsigned char* T = sp_smem + wave * (64 * kTPitch);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                *reinterpret_cast<uint16_t*>(&T[row * kTPitch + (nt * 32 + li) * 2]) = f32_to_bf16(acc[mt][nt][r]);
-            }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave's LDS operations execute in order)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3), seg = lane & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(&T[row * kTPitch + seg * 16]);
-        float* op = o_ptr[wm + row];
-        if (op != nullptr) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(op) + n0 + wn + seg * 8) = v;
-    }
-}
-
-// ---- the same projection with LDS-DMA loaders: one 128 x 192 tile per CU ---------------------------------------------
-// What the kernel above still pays: its loaders move every byte through their registers and a ds_write pass (the write
-// path is the slowest way into LDS and competes with the MFMA waves' fragment reads), two padded buffers of 39 KB leave
-// room for one tile in flight, and 1024 rows x 3 x 2048 columns in 128 x 128 tiles are 384 workgroups = 1.5 per CU.  Here:
+// time the CU's vector-memory path needs for the bytes), wait for them, write them to LDS, read fragments, multiply -- and
+// only other waves of the SIMD overlap any of it: cycle stamps (-DMLI_GEMM_TRACE) put 25 % of the k loop into load issue,
+// 24 % into waiting + LDS writes, 27 % into fragment reads + MFMAs, and neither a 128 x 128 tile nor two or three tiles in
+// flight in registers change the total (47-50 us at B=1024, D=2048 for all of them).  Round 2 split the two jobs over the
+// waves of a 512-thread workgroup (waves 4-7 load through their registers and ds_write, waves 0-3 multiply: 39-40 us);
+// that kernel's loaders still moved every byte through registers and a ds_write pass (the slowest way into LDS, competing
+// with the MFMA waves' fragment reads), two padded buffers of 39 KB left room for one tile in flight, and 128 x 128 tiles
+// over 1024 x 3 x 2048 outputs were 384 workgroups = 1.5 per CU.  This kernel replaced it in round 3:
 //   * the [Wk | Wq | Wv] columns are one sequence of 64-column sub-tiles and a workgroup takes three of them (192
 //     columns, possibly of two weights): 1024 rows -> 8 x 32 = 256 workgroups, one per CU, dealt so that an XCD's 32
 //     workgroups share 4 column tiles x all row tiles (its L2 sees 3 MB of weights + the rows);
@@ -484,7 +289,7 @@ __global__ __launch_bounds__(kSplitThreads) void gemm_bf16_split_kernel(GemmArgs
 //   * the loaders retire a tile with a counted vmcnt (the younger tile stays in flight) and a raw s_barrier; the MFMA
 //     waves (2 x 2, 64 x 96 each: 6 accumulator tiles, 5 KiB of fragments per 6 MFMAs) keep three fragment sets and read
 //     two k sub-steps ahead, across that barrier.
-// Same 32x32x16 MFMA steps in the same k order as the other two kernels: pages and q_output bit-identical (tested).
+// Same 32x32x16 MFMA steps in the same k order as the tiled kernel: pages and q_output bit-identical (tested).
 constexpr int kDmThreads = 512;
 constexpr int kDmM = 128, kDmK = 64;   // (x 192 columns = three 64-column sub-tiles)
 constexpr int kDmABytes = kDmM * kDmK * 2;         // 16384: [128][128 B]
@@ -812,9 +617,9 @@ __global__ __launch_bounds__(kDmThreads) void gemm_bf16_dma_kernel(GemmArgs g, i
 #endif
 }
 
-static thread_local int g_bf16_split = 2;  // mli_tune "gemm_bf16_split": the large decode projection runs 0 = the 128 x 64
-                                           // tiled kernel, 1 = loader waves + MFMA waves, 2 = LDS-DMA loaders (default)
-void set_bf16_split(int v) { g_bf16_split = v < 0 ? 0 : (v > 2 ? 2 : v); }
+static thread_local int g_bf16_split = 1;  // mli_tune "gemm_bf16_split": the large decode projection runs 1 (default) = the
+                                           // loader-wave / MFMA-wave kernel above, 0 = the 128 x 64 tiled kernel
+void set_bf16_split(int v) { g_bf16_split = v != 0; }
 
 int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* lengths, const uint16_t* wk,
                                     const uint16_t* wq, const uint16_t* wv, float* q, int B, int S, int D,
@@ -828,7 +633,7 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.B = B; g.S = S;
     g.compact = latest_compact(B, D);
     const int tiles_x = ceil_div_i(D, HN) * 3;
-    if (g_bf16_split == 2 && D % 64 == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
+    if (g_bf16_split && D % 64 == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
         static std::atomic<unsigned long long> dma_opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device
         int device = 0;
         (void)hipGetDevice(&device);
@@ -846,24 +651,6 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
         const int col_tiles = D / 64, row_tiles = ceil_div_i(B, kDmM);   // 3 weights x D / 192 columns
         hipLaunchKernelGGL((gemm_bf16_dma_kernel<kPagedLatest>), dim3(col_tiles * row_tiles), dim3(kDmThreads), kDmSmem, st,
                            g, col_tiles, row_tiles);
-        return launch_status();
-    }
-    if (g_bf16_split && D % kSpN == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
-        static std::atomic<unsigned long long> opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device
-        int device = 0;
-        (void)hipGetDevice(&device);
-        const unsigned long long bit = 1ull << (device & 63);
-        if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_split_kernel<kPagedLatest>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitSmem);
-            if (e != hipSuccess) return (int)e;
-            opted_in.fetch_or(bit, std::memory_order_relaxed);
-        }
-        // no row compaction here: the index build costs every workgroup ~2 us of prologue; an empty row's tile rows are
-        // zeros in, nothing out
-        g.compact = 0;
-        hipLaunchKernelGGL((gemm_bf16_split_kernel<kPagedLatest>), dim3(D / kSpN * 3, ceil_div_i(B, kSpM), 1),
-                           dim3(kSplitThreads), kSplitSmem, st, g);
         return launch_status();
     }
     if (gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {  // as the fp32 kernel: >= 2 workgroups per CU
