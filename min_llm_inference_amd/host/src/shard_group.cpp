@@ -210,25 +210,25 @@ int mli_shard_group_create(const mli_engine_config* config, int n_ranks, const i
         const Rccl& api = rccl();
         auto group = make_group(config, n_ranks, devices, emb_table, pos_table, wk, wq, wv);
         nccl_ok(api.comm_init_all(group->comms.data(), n_ranks, group->devices.data()), "ncclCommInitAll");
-        // self-proof that the communicator spans n_ranks: all-reduce of ones (grouped: one thread drives every rank here)
-        std::vector<int*> ones(n_ranks, nullptr);
+        // self-proof that the communicator spans n_ranks: all-reduce of ones (grouped: one thread drives every rank here),
+        // in the first word of every rank's gathered buffer (owned by the group: nothing to leak on the error paths)
+        const int one = 1;
+        const int zero = 0;
         for (int r = 0; r < n_ranks; ++r) {
             hip_ok(hipSetDevice(devices[r]), "hipSetDevice");
-            hip_ok(hipMalloc(reinterpret_cast<void**>(&ones[r]), sizeof(int)), "hipMalloc");
-            const int one = 1;
-            hip_ok(hipMemcpy(ones[r], &one, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+            hip_ok(hipMemcpy(group->gathered[r], &one, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
         }
         nccl_ok(api.group_start(), "ncclGroupStart");
         for (int r = 0; r < n_ranks; ++r)
-            nccl_ok(api.all_reduce(ones[r], ones[r], 1, ncclInt32, ncclSum, group->comms[r],
+            nccl_ok(api.all_reduce(group->gathered[r], group->gathered[r], 1, ncclInt32, ncclSum, group->comms[r],
                                    static_cast<hipStream_t>(group->streams[r])), "ncclAllReduce");
         nccl_ok(api.group_end(), "ncclGroupEnd");
         for (int r = 0; r < n_ranks; ++r) {
             hip_ok(hipSetDevice(devices[r]), "hipSetDevice");
             hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(group->streams[r])), "hipStreamSynchronize");
             int seen = 0;
-            hip_ok(hipMemcpy(&seen, ones[r], sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy");
-            (void)hipFree(ones[r]);
+            hip_ok(hipMemcpy(&seen, group->gathered[r], sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy");
+            hip_ok(hipMemcpy(group->gathered[r], &zero, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
             if (seen != n_ranks) throw std::runtime_error("the communicator does not span every rank");
             group->ranks_seen = seen;
         }
