@@ -402,9 +402,9 @@ int mli_f32_to_fp8(const float* src, uint8_t* dst, size_t n, void* stream);
  *   "gemm_split"       1 (default) = the fp32 GEMM with 64-row tiles (prefill, logits, projections of batches that do not
  *                      fill the chip with 128-row tiles) runs as 512-thread workgroups, four waves loading and four
  *                      multiplying, when the reduction is >= 256 long; 0 = one wave does both (identical results)
- *   "gemm_bf16_split"  1 (default) = the bf16 decode projection of a large batch (>= 1024 rows, emb_dim >= 1024 and a
- *                      multiple of 64) runs the loader-wave / MFMA-wave kernel (LDS-DMA loaders, one 128 x 192 tile per CU),
- *                      0 = the 128 x 64 tiled kernel (identical results)
+ *   "gemm_bf16_split"  1 (default) = the bf16 decode projection at emb_dim >= 1536 (any batch) or >= 1024 (from 320 rows),
+ *                      emb_dim a multiple of 64, runs the loader-wave / MFMA-wave kernel (LDS-DMA loaders, 128 x 192 tiles, one
+ *                      per CU at 1024 rows), 0 = the tiled kernels (identical results)
  *   "prefill_fused"    1 (default) = mli_[paged_]prefill runs the encoder as the fill GEMM's prologue up to emb_dim 512 and
  *                      encoder + fill as two launches beyond, 0 = always two launches, 2 = always the prologue form (fp8 pages
  *                      have the prologue form only); pages / caches are bit-identical either way

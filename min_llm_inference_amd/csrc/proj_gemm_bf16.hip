@@ -633,7 +633,11 @@ int launch_latest_paged_bf16_native(uint16_t* const* page_table, const int* leng
     g.B = B; g.S = S;
     g.compact = latest_compact(B, D);
     const int tiles_x = ceil_div_i(D, HN) * 3;
-    if (g_bf16_split && D % 64 == 0 && D >= 1024 && gemm_use_tall_tiles((int64_t)tiles_x * ceil_div_i(B, 128))) {
+    // Where the loader-wave / MFMA-wave kernel runs (tools/gemm_bf16_shape_probe.py; "gemm_tall_tiles" = 0 keeps every launch on
+    // the 64-row tiles): a workgroup takes ~20 us for its 128 x 192 tile whatever the grid, which beats the tiled kernels from
+    // emb_dim 1536 at any batch (2048: 21 vs 34 us at 128 rows, 29 vs 53 us at 1024) and at emb_dim 1024 from ~320 rows
+    // (14.3 vs 15.6 us at 512; 13.5 vs 12.0 us at 128: there the 64 x 64 tiles' 4x as many workgroups win)
+    if (g_bf16_split && D % 64 == 0 && gemm_use_tall_tiles((int64_t)1 << 40) && (D >= 1536 || (D >= 1024 && B >= 320))) {
         static std::atomic<unsigned long long> dma_opted_in{0};  // > 64 KiB of dynamic LDS: opt in once per device
         int device = 0;
         (void)hipGetDevice(&device);
