@@ -339,3 +339,4 @@ def test_null_page_inside_a_rows_length_is_skipped_not_dereferenced(oracle, mli,
     others = [b for b in range(B) if b != victim]
     assert_close(host(d["attention_result"])[others], c["attention_result"][others], what="rows with all their pages")
     assert np.isfinite(host(d["attention_result"])).all()
+
