@@ -70,3 +70,19 @@ def test_cpu_tensors_are_rejected():
         pass
     else:
         raise AssertionError("host tensors must not cross the C ABI")
+
+
+def test_public_headers_compile_as_c99_and_cxx17(tmp_path):
+    """include/*.h are the drop-in boundary for hosts in any language: plain C (cgo, ctypes, a C host) must be able to include
+    them -- no C++ types, no torch types -- and so must the C++ host mirror."""
+    import shutil
+    import subprocess
+    src = tmp_path / "headers.c"
+    src.write_text('#include "mli_kernels.h"\n#include "mli_engine.h"\n#include "mli_shard.h"\n'
+                   "int main(void) { mli_engine_config c; mli_shard_stats s; (void)c; (void)s; return mli_abi_version() > 0 ? 0 : 1; }\n")
+    inc = os.path.join(ROOT, "include")
+    assert shutil.which("gcc") and shutil.which("g++")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
