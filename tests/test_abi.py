@@ -86,3 +86,23 @@ def test_public_headers_compile_as_c99_and_cxx17(tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_a_plain_c_host_links_and_calls_the_library(tmp_path):
+    """A C program (no C++ runtime of its own, no Python) links libmli_hip.so and calls two entry points that need no GPU:
+    what a cgo / FFI host does first."""
+    import subprocess
+    libdir = os.path.join(ROOT, "min_llm_inference_amd", "lib")
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include "mli_kernels.h"\n'
+                   "int main(void) {\n"
+                   '    printf("%d %zu\\n", mli_abi_version(), mli_attention_workspace_bytes(1024, 4096, 512));\n'
+                   "    return 0;\n}\n")
+    exe = tmp_path / "host"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lmli_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    version, ws = out.stdout.split()
+    assert int(version) >= 4 and int(ws) == 65536 + 1024 * 64 * 8 + 1024 * 64 * 512 * 4
