@@ -62,6 +62,24 @@ __device__ __forceinline__ void argmax_take(float& v, int& i, float ov, int oi) 
     }
 }
 
+// One step of the argmax butterfly: of its 2 * H candidate rows a lane keeps H (the upper ones when `upper`) and
+// merges into them what its partner (lane ^ mask) held for the same rows.
+template <int H>
+__device__ __forceinline__ void argmax_butterfly_step(float (&v)[16], int (&ix)[16], bool upper, int mask) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const float send_v = upper ? v[k] : v[k + H];
+        const int send_i = upper ? ix[k] : ix[k + H];
+        float keep_v = upper ? v[k + H] : v[k];
+        int keep_i = upper ? ix[k + H] : ix[k];
+        const float ov = __shfl_xor(send_v, mask, kWave);
+        const int oi = __shfl_xor(send_i, mask, kWave);
+        const bool take = ov > keep_v || (ov == keep_v && (unsigned)oi < (unsigned)keep_i);
+        v[k] = take ? ov : keep_v;
+        ix[k] = take ? oi : keep_i;
+    }
+}
+
 // Prefill over a FLAT row list.  A new row's prompt rarely fills a 64-row tile (the reference's workload: prompts of
 // 1..64 tokens), so a grid of (row, tile-of-the-row) workgroups multiplies mostly padding.  Instead every
 // (new row z, token s < L_z) pair gets one flat index; a workgroup takes 64 consecutive pairs, whichever rows they

@@ -35,24 +35,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // KQ: 32-deep k slabs staged per tile.  Only KQ = 1 is instantiated: 128 k per barrier pair (KQ = 4) was measured
 // SLOWER for the latency-bound fp32 shapes (config 4 logits 23.8 -> 26.0 us, D = 2048 logits 61.8 -> 70.2 us) --
 // unlike the bf16 kernel, whose deep tile is a win (proj_gemm_bf16.hip).
-// One step of the argmax butterfly: of its 2 * H candidate rows a lane keeps H (the upper ones when `upper`) and
-// merges into them what its partner (lane ^ mask) held for the same rows.
-template <int H>
-__device__ __forceinline__ void argmax_butterfly_step(float (&v)[16], int (&ix)[16], bool upper, int mask) {
-#pragma unroll
-    for (int k = 0; k < H; ++k) {
-        const float send_v = upper ? v[k] : v[k + H];
-        const int send_i = upper ? ix[k] : ix[k + H];
-        float keep_v = upper ? v[k + H] : v[k];
-        int keep_i = upper ? ix[k + H] : ix[k];
-        const float ov = __shfl_xor(send_v, mask, kWave);
-        const int oi = __shfl_xor(send_i, mask, kWave);
-        const bool take = ov > keep_v || (ov == keep_v && (unsigned)oi < (unsigned)keep_i);
-        v[k] = take ? ov : keep_v;
-        ix[k] = take ? oi : keep_i;
-    }
-}
-
 template <int MODE, bool BT, bool VEC4, bool BF16 = false, int MT = 1, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 2 * kGemmThreads : kGemmThreads) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * MT;   // shadows the namespace-level 64: rows per workgroup

@@ -592,3 +592,40 @@ def test_fp32_gemm_wave_split_is_bit_identical(oracle, mli, dev, seed, B, S, D, 
     for k in res[0]:
         assert_equal(res[0][k], res[1][k], what=k)
     assert_equal(res[0]["toks"], res[0]["toks_fused"], what="fused head vs materialising head")
+
+
+@pytest.mark.parametrize("B,V,D", [(1024, 1024, 512), (1000, 1010, 576), (960, 960, 1024), (1024, 2048, 512)])
+def test_full_batch_logits_wave_split_is_bit_identical(mli, dev, B, V, D):
+    """The logits GEMM of a full batch (1024 rows x 1024 vocabulary entries and neighbours: the shapes of configs 4 / 5 and of
+    the reference's profiling workload) as loader waves + MFMA waves against one wave doing both (mli_tune "gemm_split" = 0):
+    materialised logits, the (max, lowest index) pairs of the argmax epilogue and the tokens, bit for bit -- ragged last row /
+    column tiles (rows and vocabulary entries beyond the matrix never stored, never winning), ties."""
+    from min_llm_inference_amd import ops
+    S = 32
+    res = []
+    for split in (1, 0):
+        try:
+            assert mli.mli_tune(b"gemm_split", split) == 0
+            g = torch.Generator(device=dev); g.manual_seed(B + V + D)
+            emb = torch.rand(V, D, device=dev, generator=g) * 2 - 1
+            emb[V // 3] = emb[V // 7]            # two vocabulary entries with identical logits: the lower index must win
+            emb[V - 1] = emb[V // 7]
+            wpe = torch.rand(S, D, device=dev, generator=g) * 2 - 1
+            attn = torch.rand(B, D, device=dev, generator=g) * 2 - 1
+            attn[5] = emb[V // 7] * 4.0          # a row whose maximum is that tied pair
+            x = torch.zeros(B, S, D, device=dev)
+            score = torch.full((B, V), 9.0, device=dev)
+            lengths = torch.randint(1, S - 2, (B,), dtype=torch.int32, device=dev, generator=g)
+            toks = torch.full((B,), -5, dtype=torch.int32, device=dev)
+            ops.launch_decoder(attn, emb, score, wpe, x, lengths.clone(), toks)
+            toks2 = torch.full((B,), -5, dtype=torch.int32, device=dev)
+            ops.decoder_fused(attn, emb, wpe, x.clone(), lengths.clone(), toks2)
+            res.append({"score": host(score), "toks": host(toks), "toks_fused": host(toks2)})
+        finally:
+            mli.mli_tune(b"gemm_split", 1)
+    for k in res[0]:
+        assert_equal(res[0][k], res[1][k], what=f"{k}: wave split vs one wave doing both")
+    assert_equal(res[0]["toks"], res[0]["toks_fused"], what="argmax epilogue vs materialised logits")
+    assert int(res[0]["toks"][5]) == V // 7, "ties go to the lowest index"
+    want = (host(attn).astype(np.float64) @ host(emb).astype(np.float64).T)
+    assert_close(res[0]["score"], want.astype(np.float32), thr=1e-3, what="logits vs float64")
