@@ -198,7 +198,7 @@ def test_lean_scan_many_chunks_per_row(oracle, mli, dev, chunk, tail):
     assert_close(probs, c["qkt_output"], what="probabilities")
 
 
-@pytest.mark.parametrize("seed,B,S,D", [(151, 128, 64, 512), (152, 40, 208, 1024), (153, 16, 1024, 256), (154, 3, 4096, 512)])
+@pytest.mark.parametrize("seed,B,S,D", [(151, 128, 64, 512), (152, 24, 208, 1024), (153, 16, 1024, 256), (154, 3, 4096, 512)])
 def test_paged_attention_lean_equals_paged_attention(oracle, mli, dev, seed, B, S, D):
     """The layers' composition (fill -> latest -> lean scan) leaves the same pages, q_output and attention_result as the
     reference-shaped one; it just never writes qkt_output."""
